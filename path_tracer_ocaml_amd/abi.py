@@ -1,0 +1,69 @@
+"""ctypes mirror of include/ptx.h (type declarations only -- no behaviour).
+
+Every structure here must match the C header field for field; tests/test_abi.py
+checks the sizes against the compiled library.
+"""
+import ctypes as C
+
+PTX_ABI_VERSION = 1
+
+PTX_MAT_LAMBERTIAN, PTX_MAT_METAL, PTX_MAT_DIELECTRIC = 0, 1, 2
+PTX_TEX_SOLID, PTX_TEX_CHECKER = 0, 1
+PTX_BG_BLACK, PTX_BG_SKY = 0, 1
+PTX_LEAF_SIMD, PTX_LEAF_ARRAY = 0, 1
+PTX_KERNEL_NAMES = ("generate", "trace", "shade", "accum", "film")
+PTX_N_KERNELS = 5
+
+c_double_p = C.POINTER(C.c_double)
+c_int32_p = C.POINTER(C.c_int32)
+
+
+class Material(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("texture", C.c_int32), ("index", C.c_double), ("emit", C.c_double * 3)]
+
+
+class Texture(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("width", C.c_int32), ("height", C.c_int32), ("reserved", C.c_int32),
+                ("even", C.c_double * 3), ("odd", C.c_double * 3)]
+
+
+class Camera(C.Structure):
+    _fields_ = [("lower_left_x", C.c_double), ("lower_left_y", C.c_double), ("view_x", C.c_double), ("view_y", C.c_double)]
+
+
+class Background(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("reserved", C.c_int32), ("horizon", C.c_double * 3), ("zenith", C.c_double * 3)]
+
+
+class SceneDesc(C.Structure):
+    _fields_ = [
+        ("n_spheres", C.c_int32), ("sphere_x", c_double_p), ("sphere_y", c_double_p), ("sphere_z", c_double_p),
+        ("sphere_r", c_double_p), ("sphere_material", c_int32_p),
+        ("n_vertices", C.c_int32), ("vertex_x", c_double_p), ("vertex_y", c_double_p), ("vertex_z", c_double_p),
+        ("n_triangles", C.c_int32), ("tri_indices", c_int32_p), ("tri_uv", c_double_p), ("tri_material", c_int32_p),
+        ("n_floor_triangles", C.c_int32), ("floor_vertices", c_double_p), ("floor_uv", c_double_p),
+        ("floor_material", c_int32_p),
+        ("n_materials", C.c_int32), ("materials", C.POINTER(Material)),
+        ("n_textures", C.c_int32), ("textures", C.POINTER(Texture)),
+        ("camera", Camera), ("background", Background),
+        ("leaf_kind", C.c_int32), ("length_cutoff", C.c_int32), ("num_bins", C.c_int32), ("reserved", C.c_int32),
+    ]
+
+
+class RenderParams(C.Structure):
+    _fields_ = [
+        ("width", C.c_int32), ("height", C.c_int32), ("samples_per_pixel", C.c_int32), ("max_bounces", C.c_int32),
+        ("band_rows", C.c_int32), ("band_first", C.c_int32), ("band_step", C.c_int32),
+        ("count_work", C.c_int32), ("time_kernels", C.c_int32), ("passes_per_batch", C.c_int32),
+        ("reserved", C.c_int32 * 2),
+    ]
+
+
+class Stats(C.Structure):
+    _fields_ = [
+        ("samples", C.c_int64), ("segments", C.c_int64), ("nodes_tested", C.c_int64), ("prims_tested", C.c_int64),
+        ("floor_tested", C.c_int64), ("render_ms", C.c_double),
+        ("kernel_ms", C.c_double * PTX_N_KERNELS), ("kernel_launches", C.c_int64 * PTX_N_KERNELS),
+        ("tree_nodes", C.c_int32), ("tree_depth", C.c_int32), ("tree_leaves", C.c_int32), ("leaf_slots", C.c_int32),
+        ("build_ms", C.c_double),
+    ]
