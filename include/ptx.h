@@ -178,7 +178,9 @@ const char* ptx_last_error(void);
 int32_t ptx_device_count(void);
 
 /* Builds the BVH on the host exactly as Shape_tree.create does (shape_tree.ml:252-263),
- * flattens it and uploads everything to HIP device `device`. */
+ * flattens it and uploads everything to HIP device `device`.
+ * device == -1 builds a HOST-ONLY scene (nothing uploaded): only ptx_scene_tree / ptx_scene_stats /
+ * ptx_scene_destroy accept it; every compute entry point returns an error (there is no CPU fallback). */
 ptx_scene* ptx_scene_create(const ptx_scene_desc* desc, int32_t device);
 void ptx_scene_destroy(ptx_scene* scene);
 /* copies the build statistics (tree_* and build_ms fields) */

@@ -37,6 +37,7 @@ def lib():
     L = C.CDLL(so)
     L.orc_math.restype = C.c_double
     L.orc_math.argtypes = [C.c_int, C.c_double, C.c_double]
+    L.orc_math_vec.argtypes = [C.c_int, C.c_int64, dp, dp, dp]
     L.orc_lds_alpha.argtypes = [C.c_int, dp]
     L.orc_lds_phi.restype = C.c_double
     L.orc_lds_phi.argtypes = [C.c_int]
@@ -235,6 +236,22 @@ class Scene:
             self.close()
         except Exception:
             pass
+
+
+def math_vec(fn, a, b=None):
+    """pt_math.h (mode 0) or libm (mode 1) on the host, elementwise; fn numbering as ptx_math_eval."""
+    a = f64(a)
+    bb = f64(b) if b is not None else None
+    out = np.zeros_like(a)
+    lib().orc_math_vec(fn, a.size, _dp(a), _dp(bb) if bb is not None else None, _dp(out))
+    return out
+
+
+def lds_get_vec(n_dim, offsets, dims):
+    alpha = np.zeros(n_dim)
+    lib().orc_lds_alpha(n_dim, _dp(alpha))
+    x = 0.5 + alpha[np.asarray(dims)] * (1 + np.asarray(offsets)).astype(np.float64)
+    return x - np.trunc(x)
 
 
 def set_math(mode):

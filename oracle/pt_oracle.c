@@ -63,6 +63,10 @@ ORC_API double orc_math(int fn, double a, double b) {
   return NAN;
 }
 
+ORC_API void orc_math_vec(int fn, int64_t n, const double* a, const double* b, double* out) {
+  for (int64_t i = 0; i < n; ++i) out[i] = orc_math(fn, a[i], b ? b[i] : 0.0);
+}
+
 /* ------------------------------------------------------------------ V3 (affine.ml) */
 typedef struct { double x, y, z; } v3;
 

@@ -1,0 +1,704 @@
+/* kernels.hip -- the wavefront path integrator for gfx950 (MI355X), binary64 throughout.
+ *
+ * Stages (one kernel each, connected by SoA path queues that stay resident in HBM):
+ *   generate : sampler dims 0,1 + Camera.ray            (integrator.ml:96-105, camera.ml:93-102)
+ *   trace    : Scene.intersect = ordered BVH walk + leaf packets (shape_tree.ml:198-220, lib.rs:102-178,
+ *              sphere.ml:35-54, triangle.ml:74-98, ganesha floor pre-test main.ml:286-298)
+ *   shade    : Sphere.hit / Triangle.Hit.to_hit, Material.scatter, the body of Integrator's path loop
+ *              (integrator.ml:30-66), background on a miss; survivors are compacted into the next queue
+ *   accum    : per-pixel radiance sums in pass order
+ *   film     : 3x3 binomial reconstruction + gamma (filter_kernel.ml, film_tile.ml, integrator.ml:114-128,152-154)
+ *
+ * Compiled with -ffp-contract=off; every fused multiply-add below is written out exactly where the
+ * reference writes Float.fma / _mm256_fmadd_pd.  No MFMA: there is no dense contraction on this path.
+ */
+#include <hip/hip_runtime.h>
+
+#include "pt_scene.h"
+#include "pt_vec.h"
+
+#define PT_WAVE 64
+
+/* ------------------------------------------------------------------ path queue (SoA in HBM) */
+struct PtQueue {
+  double *ox, *oy, *oz; /* ray origin */
+  double *dx, *dy, *dz; /* ray direction */
+  double *ar, *ag, *ab; /* attn0 (integrator.ml:30) */
+  double *er, *eg, *eb; /* emit0; only allocated / touched when the scene has emitters */
+  uint32_t* id;         /* slot in the batch's contribution buffer */
+  int32_t* offset;      /* sampler offset = gy*W + gx + pass*spp (integrator.ml:98) */
+  uint32_t* count;      /* number of live entries (device) */
+};
+
+struct PtHits {
+  double* t;
+  int32_t* slot; /* leaf slot index, -1 = miss; >= n_slots = floor triangle */
+  double *u, *v; /* triangle barycentrics (triangle.ml:14-20); only with triangles */
+};
+
+struct PtCounters { /* device-side work counters (count_work) */
+  unsigned long long segments, nodes, prims, floor;
+};
+
+/* ------------------------------------------------------------------ small device helpers */
+__device__ __forceinline__ int pt_lane() { return (int)(threadIdx.x & 63); }
+
+/* wave-aggregated append: returns the destination index for lanes with keep != 0 */
+__device__ __forceinline__ uint32_t pt_wave_append(uint32_t* counter, bool keep) {
+  const unsigned long long mask = __ballot(keep);
+  const uint32_t total = (uint32_t)__popcll(mask);
+  uint32_t base = 0;
+  const int lane = pt_lane();
+  const int leader = mask ? (int)__ffsll((unsigned long long)mask) - 1 : 0;
+  if (lane == leader && total) base = atomicAdd(counter, total);
+  base = (uint32_t)__shfl((int)base, leader, 64);
+  const uint32_t rank = (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+  return base + rank;
+}
+
+__device__ __forceinline__ unsigned long long pt_wave_sum(unsigned long long v) {
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  return v;
+}
+
+/* Low_discrepancy_sequence.get (low_discrepancy_sequence.ml:19-20,33-36) */
+__device__ __forceinline__ double pt_lds_get(const double* __restrict__ alpha, int offset, int dimension) {
+  const double a = alpha[dimension];
+  const double x = 0.5 + (a * (double)(1 + offset));
+  return x - pt_trunc(x);
+}
+
+/* ------------------------------------------------------------------ generate */
+struct PtGenParams {
+  int32_t width, height;   /* full image */
+  int32_t spp;
+  int32_t local_rows;      /* rows this rank renders */
+  int32_t band_rows, band_first, band_step;
+  int32_t first_pass, n_pass; /* passes in this batch */
+  int32_t tiles_x, tiles_y;   /* 8x8 pixel tiles over (width x local_rows) */
+};
+
+__device__ __forceinline__ int pt_global_row(const PtGenParams& g, int local_row) {
+  if (g.band_step <= 1) return local_row;
+  const int band_local = local_row / g.band_rows;
+  const int within = local_row - band_local * g.band_rows;
+  return (g.band_first + band_local * g.band_step) * g.band_rows + within;
+}
+
+/* Camera.ray (camera.ml:93-102): direction only; the origin is P3.origin */
+__device__ __forceinline__ V3 pt_camera_dir(const PtSceneDev& sc, double cx, double cy) {
+  return v3_normalize(v3(sc.cam_llx + (sc.cam_vx * cx), sc.cam_lly + (sc.cam_vy * cy), -1.0));
+}
+
+/* One thread per (pass, pixel); a wave covers one 8x8 pixel tile so primary rays stay coherent. */
+__global__ __launch_bounds__(256) void k_generate(PtSceneDev sc, PtGenParams g, const double* __restrict__ alpha,
+                                                  PtQueue q) {
+  const long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long per_pass = (long long)g.tiles_x * g.tiles_y * 64;
+  const int pass_in_batch = (int)(tid / per_pass);
+  const long long rem = tid - (long long)pass_in_batch * per_pass;
+  const int tile = (int)(rem >> 6);
+  const int lane = (int)(rem & 63);
+  const int tx = tile % g.tiles_x, ty = tile / g.tiles_x;
+  const int x = tx * 8 + (lane & 7), y = ty * 8 + (lane >> 3);
+  const bool valid = pass_in_batch < g.n_pass && x < g.width && y < g.local_rows;
+  const uint32_t dst = pt_wave_append(q.count, valid);
+  if (!valid) return;
+  const int gy = pt_global_row(g, y);
+  const int pass = g.first_pass + pass_in_batch;
+  /* render_tile, integrator.ml:98-105 */
+  const int offset = (gy * g.width) + x + (pass * g.spp);
+  const double widthf = 1.0 / (double)g.width, heightf = 1.0 / (double)g.height;
+  const double dxs = pt_lds_get(alpha, offset, 0), dys = pt_lds_get(alpha, offset, 1);
+  const double cx = ((double)x + dxs) * widthf;
+  const double cy = 1.0 - (((double)gy + dys) * heightf);
+  const V3 dir = pt_camera_dir(sc, cx, cy);
+  q.ox[dst] = 0.0; q.oy[dst] = 0.0; q.oz[dst] = 0.0;
+  q.dx[dst] = dir.x; q.dy[dst] = dir.y; q.dz[dst] = dir.z;
+  q.ar[dst] = 1.0; q.ag[dst] = 1.0; q.ab[dst] = 1.0; /* Color.white */
+  if (sc.has_emit) { q.er[dst] = 0.0; q.eg[dst] = 0.0; q.eb[dst] = 0.0; } /* Color.black */
+  q.id[dst] = (uint32_t)((long long)pass_in_batch * g.width * g.local_rows + (long long)y * g.width + x);
+  q.offset[dst] = offset;
+}
+
+/* explicit (x, y, pass) triples: ptx_trace_samples */
+__global__ __launch_bounds__(256) void k_generate_list(PtSceneDev sc, int width, int height, int spp, long long n,
+                                                       const int32_t* __restrict__ xs, const int32_t* __restrict__ ys,
+                                                       const int32_t* __restrict__ passes,
+                                                       const double* __restrict__ alpha, PtQueue q) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const bool valid = i < n;
+  const uint32_t dst = pt_wave_append(q.count, valid);
+  if (!valid) return;
+  const int x = xs[i], gy = ys[i], pass = passes[i];
+  const int offset = (gy * width) + x + (pass * spp);
+  const double widthf = 1.0 / (double)width, heightf = 1.0 / (double)height;
+  const double dxs = pt_lds_get(alpha, offset, 0), dys = pt_lds_get(alpha, offset, 1);
+  const double cx = ((double)x + dxs) * widthf;
+  const double cy = 1.0 - (((double)gy + dys) * heightf);
+  const V3 dir = pt_camera_dir(sc, cx, cy);
+  q.ox[dst] = 0.0; q.oy[dst] = 0.0; q.oz[dst] = 0.0;
+  q.dx[dst] = dir.x; q.dy[dst] = dir.y; q.dz[dst] = dir.z;
+  q.ar[dst] = 1.0; q.ag[dst] = 1.0; q.ab[dst] = 1.0;
+  if (sc.has_emit) { q.er[dst] = 0.0; q.eg[dst] = 0.0; q.eb[dst] = 0.0; }
+  q.id[dst] = (uint32_t)i;
+  q.offset[dst] = offset;
+}
+
+/* ------------------------------------------------------------------ trace */
+/* Bbox.is_hit (bbox.ml:40-56) with Base's NaN-propagating min/max */
+__device__ __forceinline__ bool pt_slab_hit(const PtNode& n, V3 o, V3 inv, double t_min, double t_max) {
+  const double t0x = (n.mn[0] - o.x) * inv.x, t0y = (n.mn[1] - o.y) * inv.y, t0z = (n.mn[2] - o.z) * inv.z;
+  const double t1x = (n.mx[0] - o.x) * inv.x, t1y = (n.mx[1] - o.y) * inv.y, t1z = (n.mx[2] - o.z) * inv.z;
+  const double a = pt_base_max(pt_base_min(t0x, t1x), pt_base_max(pt_base_min(t0y, t1y), pt_base_min(t0z, t1z)));
+  const double b = pt_base_min(pt_base_max(t0x, t1x), pt_base_min(pt_base_max(t0y, t1y), pt_base_max(t0z, t1z)));
+  const double lo = pt_base_max(t_min, a);
+  const double hi = pt_base_min(t_max, b);
+  return lo <= hi;
+}
+
+/* Triangle.intersect (triangle.ml:74-98) */
+__device__ __forceinline__ bool pt_triangle_intersect(V3 a, V3 b, V3 c, V3 o, V3 dir, double t_min, double t_max,
+                                                      double* t_out, double* u_out, double* v_out) {
+  const double epsilon = 1e-6;
+  const V3 e1 = v3_sub(b, a);
+  const V3 e2 = v3_sub(c, a);
+  const V3 pvec = v3_cross(dir, e2);
+  const double det = v3_dot(e1, pvec);
+  if (pt_fabs(det) < epsilon) return false;
+  const double det_inv = 1.0 / det;
+  const V3 tvec = v3_sub(o, a);
+  const double u = det_inv * v3_dot(tvec, pvec);
+  const V3 qvec = v3_cross(tvec, e1);
+  const double v = det_inv * v3_dot(dir, qvec);
+  if (0.0 <= u && u <= 1.0 && 0.0 <= v && u + v <= 1.0) {
+    const double t_hit = det_inv * v3_dot(e2, qvec);
+    if (t_min <= t_hit && t_hit <= t_max) {
+      *t_out = t_hit;
+      *u_out = u;
+      *v_out = v;
+      return true;
+    }
+  }
+  return false;
+}
+
+__device__ __forceinline__ V3 pt_load_v3(const double* p) { return v3(p[0], p[1], p[2]); }
+
+/* Sphere.intersect, scalar (--no-simd / Array_leaf) form, sphere.ml:35-54 */
+__device__ __forceinline__ bool pt_sphere_intersect_scalar(V3 center, double radius, V3 o, V3 d, double t_min,
+                                                           double t_max, double* t_out) {
+  const double r2 = radius * radius;
+  const V3 f = v3_sub(center, o);
+  const double bp = v3_dot(f, d);
+  const double a = v3_quadrance(d);
+  const double discrim = r2 - v3_quadrance(v3_sub(v3_scale(d, bp / a), f));
+  if (discrim < 0.0) return false;
+  const double sign_bp = (bp >= 0.0) ? 1.0 : -1.0;
+  const double q = pt_fma(sign_bp, pt_sqrt(a * discrim), bp);
+  const double c = v3_quadrance(f) - r2;
+  const double t_hit = (c > 0.0) ? c / q : q / a;
+  if (t_min <= t_hit && t_hit <= t_max) {
+    *t_out = t_hit;
+    return true;
+  }
+  return false;
+}
+
+/* One lane = one ray.  The traversal stack (far children only) lives in LDS, one column per lane,
+ * so pushes/pops are conflict-free ds_write_b32 / ds_read_b32.  A far child's bbox is tested when it
+ * is POPPED, against the closest hit so far -- exactly the t_max the reference's recursion passes
+ * (shape_tree.ml:210-216). */
+template <int MODE, bool COUNT>
+__global__ __launch_bounds__(256) void k_trace(PtSceneDev sc, PtQueue q, PtHits hits, int stack_depth,
+                                               PtCounters* counters, const uint32_t* n_override) {
+  extern __shared__ uint32_t lds_stack[];
+  const int lane = pt_lane();
+  const int wave_in_block = (int)(threadIdx.x >> 6);
+  uint32_t* stack = lds_stack + (size_t)wave_in_block * stack_depth * PT_WAVE + lane;
+  const uint32_t n = n_override ? *n_override : *q.count;
+  const uint32_t waves_per_block = blockDim.x >> 6;
+  const uint32_t gwave = blockIdx.x * waves_per_block + wave_in_block;
+  const uint32_t nwaves = gridDim.x * waves_per_block;
+  unsigned long long c_nodes = 0, c_prims = 0, c_floor = 0, c_seg = 0;
+
+  for (uint32_t chunk = gwave; (unsigned long long)chunk * PT_WAVE < n; chunk += nwaves) {
+    const uint32_t i = chunk * PT_WAVE + lane;
+    if (i >= n) continue;
+    const V3 o = v3(q.ox[i], q.oy[i], q.oz[i]);
+    const V3 d = v3(q.dx[i], q.dy[i], q.dz[i]);
+    const V3 inv = v3(1.0 / d.x, 1.0 / d.y, 1.0 / d.z); /* Ray.create, ray.ml:7-10 */
+    /* dirs, shape_tree.ml:201 */
+    const uint32_t dirs = (d.x >= 0.0 ? 1u : 0u) | (d.y >= 0.0 ? 2u : 0u) | (d.z >= 0.0 ? 4u : 0u);
+    const double t_min = 0.0;
+    double t_best = PT_MAX_FINITE;
+    int slot_best = -1;
+    double u_best = 0.0, v_best = 0.0;
+    if (COUNT) c_seg++;
+
+    /* ganesha Floor.intersect (main.ml:247-256): f1 then f2, the first hit clips t_max for the tree */
+    if (MODE == PT_MODE_ARRAY && sc.n_floor > 0) {
+      for (int f = 0; f < sc.n_floor; ++f) {
+        const double* tv = sc.tri + (size_t)(sc.n_slots + f) * 10;
+        double t, u, v;
+        if (COUNT) c_floor++;
+        if (pt_triangle_intersect(pt_load_v3(tv), pt_load_v3(tv + 3), pt_load_v3(tv + 6), o, d, 0.0, PT_MAX_FINITE,
+                                  &t, &u, &v)) {
+          t_best = t;
+          u_best = u;
+          v_best = v;
+          slot_best = sc.n_slots + f;
+          break;
+        }
+      }
+    }
+
+    /* packet constants of spheres_intersect_aux (lib.rs:115-117): a is the UNFUSED scalar dot */
+    double qa = 0.0, one_over_a = 0.0;
+    if (MODE == PT_MODE_SIMD) {
+      qa = d.x * d.x + d.y * d.y + d.z * d.z;
+      one_over_a = 1.0 / qa;
+    }
+
+    if (sc.n_nodes > 0) {
+      int sp = 0;
+      uint32_t node = 0;
+      for (;;) {
+        const PtNode* np = sc.nodes + node;
+        PtNode nd;
+        nd.mn[0] = np->mn[0]; nd.mn[1] = np->mn[1]; nd.mn[2] = np->mn[2];
+        nd.mx[0] = np->mx[0]; nd.mx[1] = np->mx[1]; nd.mx[2] = np->mx[2];
+        nd.a = np->a; nd.b = np->b;
+        if (COUNT) c_nodes++;
+        bool descend = false;
+        if (pt_slab_hit(nd, o, inv, t_min, t_best)) {
+          const uint32_t axis = nd.b >> 30;
+          if (axis == PT_NODE_LEAF_AXIS) {
+            const int first = (int)nd.a;
+            const int len = (int)(nd.b & 0x3fffffffu);
+            if (COUNT) c_prims += (unsigned long long)len;
+            if (MODE == PT_MODE_SIMD) {
+              /* spheres_intersect_aux, lib.rs:102-178, one packet lane per iteration; padded NaN slots
+               * produce NaN and are never selected, exactly like the AVX lanes */
+              for (int k = 0; k < len; ++k) {
+                const double* s = sc.sph + (size_t)(first + k) * 4;
+                const double fx = s[0] - o.x, fy = s[1] - o.y, fz = s[2] - o.z;
+                const double r2 = s[3] * s[3];
+                const double c = pt_fma(fx, fx, pt_fma(fy, fy, fz * fz)) - r2;
+                const double bp = pt_fma(fx, d.x, pt_fma(fy, d.y, fz * d.z));
+                const double bp_over_a = bp * one_over_a;
+                const double wx = pt_fma(d.x, bp_over_a, -fx);
+                const double wy = pt_fma(d.y, bp_over_a, -fy);
+                const double wz = pt_fma(d.z, bp_over_a, -fz);
+                const double wq = pt_fma(wx, wx, pt_fma(wy, wy, wz * wz));
+                const double disc = r2 - wq;
+                /* lanes whose discriminant has its sign bit set (or is NaN) end up NaN: skip them */
+                if (disc == disc && !pt_signbit(disc)) {
+                  const double q_rhs = pt_sqrt(qa * disc);
+                  const double qq = pt_signbit(bp) ? (bp - q_rhs) : (bp + q_rhs);
+                  const double t = pt_signbit(c) ? (qq * one_over_a) : (c / qq);
+                  /* not (t < t_min), not (t > t_max), then `t <= t_found` (last index wins ties) */
+                  if (!(t < t_min) && t <= t_best) {
+                    t_best = t;
+                    slot_best = first + k;
+                  }
+                }
+              }
+            } else {
+              /* Array_leaf.intersect, shape_tree.ml:299-311: shrinking t_max, later element wins ties */
+              for (int k = 0; k < len; ++k) {
+                const int slot = first + k;
+                if (sc.slot_kind[slot] == PT_SLOT_SPHERE) {
+                  const double* s = sc.sph + (size_t)slot * 4;
+                  double t;
+                  if (pt_sphere_intersect_scalar(v3(s[0], s[1], s[2]), s[3], o, d, t_min, t_best, &t)) {
+                    t_best = t;
+                    slot_best = slot;
+                  }
+                } else {
+                  const double* tv = sc.tri + (size_t)slot * 10;
+                  double t, u, v;
+                  if (pt_triangle_intersect(pt_load_v3(tv), pt_load_v3(tv + 3), pt_load_v3(tv + 6), o, d, t_min,
+                                            t_best, &t, &u, &v)) {
+                    t_best = t;
+                    u_best = u;
+                    v_best = v;
+                    slot_best = slot;
+                  }
+                }
+              }
+            }
+          } else {
+            /* Branch: near child first (shape_tree.ml:209), far child deferred */
+            const uint32_t lhs = nd.a, rhs = nd.b & 0x3fffffffu;
+            const bool lhs_first = (dirs >> axis) & 1u;
+            const uint32_t near_c = lhs_first ? lhs : rhs, far_c = lhs_first ? rhs : lhs;
+            stack[sp * PT_WAVE] = far_c;
+            ++sp;
+            node = near_c;
+            descend = true;
+          }
+        }
+        if (!descend) {
+          if (sp == 0) break;
+          --sp;
+          node = stack[sp * PT_WAVE];
+        }
+      }
+    }
+    hits.t[i] = t_best;
+    hits.slot[i] = slot_best;
+    if (MODE == PT_MODE_ARRAY && sc.has_triangles) {
+      hits.u[i] = u_best;
+      hits.v[i] = v_best;
+    }
+  }
+  if (COUNT) {
+    c_nodes = pt_wave_sum(c_nodes);
+    c_prims = pt_wave_sum(c_prims);
+    c_floor = pt_wave_sum(c_floor);
+    c_seg = pt_wave_sum(c_seg);
+    if (lane == 0) {
+      atomicAdd(&counters->nodes, c_nodes);
+      atomicAdd(&counters->prims, c_prims);
+      atomicAdd(&counters->floor, c_floor);
+      atomicAdd(&counters->segments, c_seg);
+    }
+  }
+}
+
+/* ------------------------------------------------------------------ shade */
+struct Quat {
+  double r;
+  V3 v;
+};
+/* Quaternion.mul (quaternion.ml:25-32) */
+__device__ __forceinline__ Quat pt_quat_mul(Quat a, Quat b) {
+  Quat o;
+  o.r = (a.r * b.r) - v3_dot(a.v, b.v);
+  o.v = v3_add(v3_add(v3_cross(a.v, b.v), v3_scale(b.v, a.r)), v3_scale(a.v, b.r));
+  return o;
+}
+/* Quaternion.transform t v = ((t * (0, v)) * conj t).v (quaternion.ml:34-42) */
+__device__ __forceinline__ V3 pt_quat_transform(Quat t, V3 v) {
+  Quat p;
+  p.r = 0.0;
+  p.v = v;
+  Quat c;
+  c.r = t.r;
+  c.v = v3_neg(t.v);
+  return pt_quat_mul(pt_quat_mul(t, p), c).v;
+}
+/* Shader_space.create (shader_space.ml:11-23) + Quaternion.normalize (quaternion.ml:11-15) */
+__device__ __forceinline__ Quat pt_shader_rotation(V3 normal) {
+  const double epsilon = 1e-9;
+  Quat q;
+  if (normal.z > 1.0 - epsilon) {
+    q.r = 1.0;
+    q.v = v3(0.0, 0.0, 0.0);
+  } else if (normal.z < epsilon - 1.0) {
+    q.r = 0.0;
+    q.v = v3(0.0, 1.0, 0.0);
+  } else {
+    const double r = 1.0 + normal.z;
+    const V3 v = v3(normal.y, -normal.x, 0.0);
+    const double s = 1.0 / pt_hypot(pt_hypot(r, v.x), pt_hypot(v.y, v.z));
+    q.r = r * s;
+    q.v = v3_scale(v, s);
+  }
+  return q;
+}
+__device__ __forceinline__ Quat pt_quat_conj(Quat q) {
+  Quat c;
+  c.r = q.r;
+  c.v = v3_neg(q.v);
+  return c;
+}
+
+/* Texture.eval (texture.ml:16-31) */
+__device__ __forceinline__ V3 pt_texture_eval(const PtTexture& t, double u, double v) {
+  if (t.kind == 0) return v3(t.even[0], t.even[1], t.even[2]);
+  const double width = (double)(t.width - 1), height = (double)(t.height - 1);
+  const double xp = u * width, yp = v * height;
+  const long long px = ((long long)xp) & 1, py = ((long long)yp) & 1; /* Float.to_int a land 1 */
+  if (px == py) return v3(t.even[0], t.even[1], t.even[2]);
+  return v3(t.odd[0], t.odd[1], t.odd[2]);
+}
+
+/* schlick_reflectance (material.ml:16-20) */
+__device__ __forceinline__ double pt_schlick(double cos_theta, double index) {
+  const double qd = (1.0 - index) / (1.0 + index);
+  const double r0 = qd * qd;
+  return r0 + ((1.0 - r0) * pt_pow5(1.0 - cos_theta));
+}
+
+/* Scene.background (shirley_spheres/bin/main.ml:104-110) */
+__device__ __forceinline__ V3 pt_background(const PtSceneDev& sc, V3 dir) {
+  if (sc.bg_kind == 0) return v3(0.0, 0.0, 0.0);
+  const V3 d = v3_normalize(dir);
+  const double t = 0.5 * (v3_dot(d, v3(0.0, 1.0, 0.0)) + 1.0);
+  return v3_lerp(t, v3(sc.bg_horizon[0], sc.bg_horizon[1], sc.bg_horizon[2]),
+                 v3(sc.bg_zenith[0], sc.bg_zenith[1], sc.bg_zenith[2]));
+}
+
+struct PtContrib {
+  double *r, *g, *b;
+};
+
+/* The body of `loop` in Integrator.path_tracer (integrator.ml:30-66) for one segment of every live path:
+ * consumes (ray, hit), writes either the path's final colour or the next ray into `out`. */
+template <bool EMIT>
+__global__ __launch_bounds__(256) void k_shade(PtSceneDev sc, PtQueue q, PtHits hits, PtQueue out, PtContrib contrib,
+                                               const double* __restrict__ alpha, int bounce, int last_bounce) {
+  const uint32_t n = *q.count;
+  const uint32_t waves_per_block = blockDim.x >> 6;
+  const uint32_t gwave = blockIdx.x * waves_per_block + (threadIdx.x >> 6);
+  const uint32_t nwaves = gridDim.x * waves_per_block;
+  const int lane = pt_lane();
+  const double pi = 3.14159265358979323846;
+
+  for (uint32_t chunk = gwave; (unsigned long long)chunk * PT_WAVE < n; chunk += nwaves) {
+    const uint32_t i = chunk * PT_WAVE + lane;
+    const bool live = i < n;
+    bool keep = false;
+    V3 n_o = v3(0, 0, 0), n_d = v3(0, 0, 0), n_attn = v3(0, 0, 0), n_emit = v3(0, 0, 0);
+    uint32_t id = 0;
+    int offset = 0;
+    if (live) {
+      const V3 o = v3(q.ox[i], q.oy[i], q.oz[i]);
+      const V3 d = v3(q.dx[i], q.dy[i], q.dz[i]);
+      const V3 attn0 = v3(q.ar[i], q.ag[i], q.ab[i]);
+      V3 emit0 = v3(0.0, 0.0, 0.0);
+      if (EMIT) emit0 = v3(q.er[i], q.eg[i], q.eb[i]);
+      id = q.id[i];
+      offset = q.offset[i];
+      const int slot = hits.slot[i];
+      V3 result = v3(0, 0, 0);
+      bool done = true;
+      if (slot < 0) {
+        /* None -> add_mul emit0 attn0 (background ray), integrator.ml:36 */
+        result = v3_fma(attn0, pt_background(sc, d), emit0);
+      } else {
+        const double t_hit = hits.t[i];
+        const uint8_t kind = sc.slot_kind[slot];
+        const PtMaterial m = sc.materials[sc.slot_material[slot]];
+        V3 point, normal;
+        double tu = 0.0, tv = 0.0;
+        bool hit_front;
+        const bool need_uv = (m.kind != 2) && (sc.textures[m.texture].kind != 0);
+        if (kind == PT_SLOT_SPHERE) {
+          /* Sphere.hit (sphere.ml:56-69) */
+          const double* s = sc.sph + (size_t)slot * 4;
+          const V3 center = v3(s[0], s[1], s[2]);
+          point = v3_add(o, v3_scale(d, t_hit)); /* Ray.point_at, ray.ml:15 */
+          normal = v3_normalize(v3_sub(point, center));
+          hit_front = v3_dot(d, normal) < 0.0;
+          if (!hit_front) normal = v3_neg(normal);
+          if (need_uv) { /* tex_coord (sphere.ml:25-33) feeds Texture.eval only */
+            const double one_over_pi = 1.0 / pi, one_over_two_pi = 1.0 / (2.0 * pi);
+            const double theta = pt_acos(-normal.y);
+            const double phi = pi + pt_atan2(-normal.z, normal.x);
+            tu = phi * one_over_two_pi;
+            tv = theta * one_over_pi;
+          }
+        } else {
+          /* Triangle.Hit.to_hit (triangle.ml:43-64) */
+          const double* tvx = sc.tri + (size_t)slot * 10;
+          const V3 a = pt_load_v3(tvx), b = pt_load_v3(tvx + 3), c = pt_load_v3(tvx + 6);
+          const V3 g_normal = v3_normalize(v3_cross(v3_sub(b, a), v3_sub(c, a)));
+          const double u = hits.u[i], v = hits.v[i];
+          const double w = 1.0 - u - v;
+          point = v3_add(v3_add(v3_scale(a, w), v3_scale(b, u)), v3_scale(c, v));
+          const double* uv = sc.tri_uv + (size_t)slot * 6;
+          tu = (uv[0] * w) + (uv[2] * u) + (uv[4] * v);
+          tv = (uv[1] * w) + (uv[3] * u) + (uv[5] * v);
+          hit_front = v3_dot(d, g_normal) < 0.0;
+          normal = hit_front ? g_normal : v3_neg(g_normal);
+        }
+        const Quat rot = pt_shader_rotation(normal);
+        const Quat rot_inv = pt_quat_conj(rot);
+        const V3 omega_i = pt_quat_transform(rot, v3_neg(d)); /* Shader_space.omega_i */
+        const V3 emit = EMIT ? v3(m.emit[0], m.emit[1], m.emit[2]) : v3(0.0, 0.0, 0.0);
+        /* take_2d (), integrator.ml:20-28,39: dims 2+2k, 3+2k for the k-th hit */
+        const double su = pt_lds_get(alpha, offset, 2 + 2 * bounce);
+        const double sv = pt_lds_get(alpha, offset, 3 + 2 * bounce);
+
+        /* Material.scatter (material.ml:22-57) */
+        int sc_kind; /* 0 Absorb, 1 Specular, 2 Diffuse */
+        V3 attenuation = v3(1.0, 1.0, 1.0);
+        V3 wo = v3(0, 0, 0); /* shader-space direction of the scattered ray */
+        if (m.kind == 0) {
+          sc_kind = 2;
+          attenuation = pt_texture_eval(sc.textures[m.texture], tu, tv);
+        } else if (m.kind == 1) {
+          const V3 omega_r = v3(-omega_i.x, -omega_i.y, omega_i.z); /* Shader_space.reflect */
+          if (omega_r.z <= 0.0) {
+            sc_kind = 0;
+          } else {
+            sc_kind = 1;
+            const V3 a = pt_texture_eval(sc.textures[m.texture], tu, tv);
+            const double sp5 = pt_pow5(1.0 - omega_i.z);
+            const V3 c = v3_scale(v3_sub(v3(1.0, 1.0, 1.0), a), sp5);
+            attenuation = v3_add(a, c);
+            wo = omega_r;
+          }
+        } else {
+          sc_kind = 1;
+          const double index = m.index, index_inv = 1.0 / m.index;
+          const double wi_z = omega_i.z;
+          const double c = wi_z < 0.0 ? 0.0 : (1.0 < wi_z ? 1.0 : wi_z); /* Float.clamp_exn */
+          const double sn = pt_sqrt(1.0 - c * c);
+          const double refract_ratio = hit_front ? index_inv : index;
+          if (refract_ratio * sn > 1.0 || pt_schlick(c, refract_ratio) > su) {
+            wo = v3(-omega_i.x, -omega_i.y, omega_i.z);
+          } else {
+            /* Shader_space.refract (shader_space.ml:41-49) */
+            const double cc = pt_base_min(omega_i.z, 1.0);
+            const V3 perp = v3_scale(v3_sub(v3(0.0, 0.0, cc), omega_i), refract_ratio);
+            const V3 para = v3(0.0, 0.0, -pt_sqrt(pt_fabs(1.0 - v3_quadrance(perp))));
+            wo = v3_add(perp, para);
+          }
+        }
+
+        if (sc_kind == 0) {
+          result = v3_fma(attn0, emit, emit0); /* Absorb, integrator.ml:41 */
+        } else {
+          bool scatter_ok = true;
+          if (sc_kind == 2) {
+            /* Pdf.sample / Pdf.eval (pdf.ml:5-15, shader_space.ml:56-64) */
+            const double r = pt_sqrt(su);
+            const double theta = sv * 2.0 * pi;
+            double sn, cs;
+            pt_sincos(theta, &sn, &cs);
+            wo = v3(r * cs, r * sn, pt_sqrt(1.0 - su));
+            const double diffuse_pd = (wo.z < 0.0) ? 0.0 : wo.z / pi;
+            if (diffuse_pd == 0.0) {
+              scatter_ok = false;
+            } else {
+              const double pd = diffuse_pd / diffuse_pd; /* divisor = Pdf.eval diffuse_plus_light = the same */
+              if (!pt_isfinite(pd)) scatter_ok = false;
+              else attenuation = v3_scale(attenuation, pd);
+            }
+          }
+          if (!scatter_ok) {
+            result = v3_fma(attn0, emit, emit0); /* integrator.ml:53,58 */
+          } else {
+            /* Shader_space.world_ray (shader_space.ml:51-54) */
+            const V3 dir = pt_quat_transform(rot_inv, wo);
+            n_o = v3_add(point, v3_scale(dir, 1e-3));
+            n_d = dir;
+            n_emit = v3_fma(attenuation, emit0, emit); /* add_mul emit attenuation emit0 */
+            n_attn = v3_mul(attenuation, attn0);
+            if (last_bounce) {
+              /* the recursive call sees max_bounces <= 0: add_mul emit0 attn0 Color.black (integrator.ml:31-32) */
+              result = v3_fma(n_attn, v3(0.0, 0.0, 0.0), n_emit);
+            } else {
+              done = false;
+            }
+          }
+        }
+      }
+      if (done) {
+        contrib.r[id] = result.x;
+        contrib.g[id] = result.y;
+        contrib.b[id] = result.z;
+      } else {
+        keep = true;
+      }
+    }
+    const uint32_t dst = pt_wave_append(out.count, keep);
+    if (keep) {
+      out.ox[dst] = n_o.x; out.oy[dst] = n_o.y; out.oz[dst] = n_o.z;
+      out.dx[dst] = n_d.x; out.dy[dst] = n_d.y; out.dz[dst] = n_d.z;
+      out.ar[dst] = n_attn.x; out.ag[dst] = n_attn.y; out.ab[dst] = n_attn.z;
+      if (EMIT) { out.er[dst] = n_emit.x; out.eg[dst] = n_emit.y; out.eb[dst] = n_emit.z; }
+      out.id[dst] = id;
+      out.offset[dst] = offset;
+    }
+  }
+}
+
+/* ------------------------------------------------------------------ accumulate + film */
+/* raw[pix] += contributions of this batch's passes, in pass order (the order render_tile's pass loop
+ * feeds the film, integrator.ml:96) */
+__global__ __launch_bounds__(256) void k_accum(PtContrib contrib, long long npix, int n_pass, double* __restrict__ raw) {
+  const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= npix) return;
+  double r = raw[3 * p], g = raw[3 * p + 1], b = raw[3 * p + 2];
+  for (int k = 0; k < n_pass; ++k) {
+    const long long j = (long long)k * npix + p;
+    r = r + contrib.r[j];
+    g = g + contrib.g[j];
+    b = b + contrib.b[j];
+  }
+  raw[3 * p] = r;
+  raw[3 * p + 1] = g;
+  raw[3 * p + 2] = b;
+}
+
+struct PtFilm3 {
+  double w[9];
+};
+/* Film_tile.write_pixel splats sample s at its own pixel q to q + (dx, dy) with weight k[dy][dx]
+ * (film_tile.ml:23-45); stitch_tile drops what falls outside the image (integrator.ml:114-128).  As a
+ * gather: P = sum_taps k[dy][dx] * S(P - (dx, dy)) over in-image neighbours, then sqrt(v * (1/spp)). */
+__global__ __launch_bounds__(256) void k_film(const double* __restrict__ raw, int width, int height, double spp_inv,
+                                              PtFilm3 kern, double* __restrict__ out) {
+  const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= (long long)width * height) return;
+  const int x = (int)(p % width), y = (int)(p / width);
+  double r = 0.0, g = 0.0, b = 0.0;
+  int k = 0;
+  for (int dy = -1; dy <= 1; ++dy) {
+    for (int dx = -1; dx <= 1; ++dx, ++k) {
+      const int sx = x - dx, sy = y - dy;
+      if (sx < 0 || sx >= width || sy < 0 || sy >= height) continue;
+      const double* s = raw + ((long long)sy * width + sx) * 3;
+      const double wgt = kern.w[k];
+      r = pt_fma(wgt, s[0], r);
+      g = pt_fma(wgt, s[1], g);
+      b = pt_fma(wgt, s[2], b);
+    }
+  }
+  out[3 * p] = pt_sqrt(r * spp_inv);
+  out[3 * p + 1] = pt_sqrt(g * spp_inv);
+  out[3 * p + 2] = pt_sqrt(b * spp_inv);
+}
+
+/* ------------------------------------------------------------------ unit entry points */
+__global__ void k_lds_sample(const double* __restrict__ alpha, long long n, const int32_t* __restrict__ offsets,
+                             const int32_t* __restrict__ dims, double* __restrict__ out) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = pt_lds_get(alpha, offsets[i], dims[i]);
+}
+
+__global__ void k_math_eval(int fn, long long n, const double* __restrict__ a, const double* __restrict__ b,
+                            double* __restrict__ out) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const double x = a[i], y = b ? b[i] : 0.0;
+  double r;
+  switch (fn) {
+    case 0: r = pt_hypot(x, y); break;
+    case 1: r = pt_sin(x); break;
+    case 2: r = pt_cos(x); break;
+    case 3: r = pt_acos(x); break;
+    case 4: r = pt_atan2(x, y); break;
+    case 5: r = pt_pow5(x); break;
+    case 6: r = pt_sqrt(x); break;
+    case 7: r = x / y; break;
+    case 8: r = pt_fma(x, y, y); break;
+    default: r = pt_nan(); break;
+  }
+  out[i] = r;
+}
+
+/* copies explicit rays into a queue (ptx_intersect_rays) */
+__global__ void k_load_rays(long long n, const double* __restrict__ o, const double* __restrict__ d, PtQueue q) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  q.ox[i] = o[3 * i]; q.oy[i] = o[3 * i + 1]; q.oz[i] = o[3 * i + 2];
+  q.dx[i] = d[3 * i]; q.dy[i] = d[3 * i + 1]; q.dz[i] = d[3 * i + 2];
+}
+
+#include "ptx_api.inc"

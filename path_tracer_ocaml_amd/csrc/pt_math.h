@@ -28,6 +28,7 @@
 #include <stdint.h>
 
 #if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
 #define PT_HD static __host__ __device__ __forceinline__
 #else
 #define PT_HD static inline

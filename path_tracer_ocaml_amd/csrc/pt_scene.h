@@ -1,0 +1,83 @@
+/* pt_scene.h -- the flattened scene as it lives in HBM, shared by the host builder
+ * (bvh_build.cpp) and the HIP kernels (kernels.hip).
+ *
+ * Layout decisions:
+ *  - BVH node = one 64-byte record (bbox 6 x f64 + two u32 links), 64-byte aligned: a lane
+ *    that visits a node touches exactly one cache line / four 16-byte LDS reads.
+ *  - leaf primitive slots are stored in LEAF ORDER, contiguous per leaf ("packets"):
+ *      sphere slot   = 4 x f64 {x, y, z, r}        (32 B; NaN padding slots for Simd_leaf)
+ *      triangle slot = 10 x f64 {a, b, c, pad}     (80 B, 16-byte aligned)
+ *    so a leaf is one contiguous burst, never an index gather.
+ *  - a slot's shading data (material id, kind, primitive id, triangle UVs) sits in
+ *    separate arrays touched only by the shade stage for the ONE slot that was hit.
+ */
+#ifndef PT_SCENE_H
+#define PT_SCENE_H
+
+#include <stdint.h>
+
+#define PT_NODE_LEAF_AXIS 3u /* axis code stored in the two top bits of `b` for leaves */
+#define PT_MAX_FINITE 1.7976931348623157e308
+
+/* One BVH node, 64 bytes.  Tree.t = Bbox.t * (Leaf | Branch {axis; lhs; rhs}), shape_tree.ml:153-161 */
+struct __attribute__((aligned(64))) PtNode {
+  double mn[3];
+  double mx[3];
+  uint32_t a; /* branch: index of lhs        | leaf: first slot            */
+  uint32_t b; /* branch: index of rhs + axis<<30 | leaf: slot count + 3<<30 */
+  uint32_t pad[2];
+};
+
+#define PT_SLOT_SPHERE 0
+#define PT_SLOT_TRIANGLE 1
+#define PT_SLOT_PAD 2 /* NaN padding slot of a Simd_leaf packet */
+
+/* scene "mode" = which Leaf implementation the tree was built with */
+#define PT_MODE_SIMD 0  /* Simd_leaf packets: every slot a sphere, Rust x86 arithmetic */
+#define PT_MODE_ARRAY 1 /* Array_leaf: spheres (scalar Sphere.intersect) and/or triangles */
+
+struct PtMaterial { /* 48 B */
+  int32_t kind;
+  int32_t texture;
+  double index;
+  double emit[3];
+  double pad;
+};
+struct PtTexture { /* 64 B */
+  int32_t kind;
+  int32_t width, height;
+  int32_t pad;
+  double even[3];
+  double odd[3];
+  double pad2;
+};
+
+/* everything a kernel needs, passed by value (pointers are device pointers) */
+struct PtSceneDev {
+  const PtNode* nodes;
+  int32_t n_nodes;
+  int32_t depth;       /* tree depth = max traversal stack entries */
+  int32_t mode;        /* PT_MODE_* */
+  int32_t n_slots;
+  const double* sph;   /* n_slots x 4 (valid where slot_kind != TRIANGLE) */
+  const double* tri;   /* n_slots x 10 (valid where slot_kind == TRIANGLE); NULL if no triangles */
+  const double* tri_uv;/* n_slots x 6 */
+  const uint8_t* slot_kind;
+  const int32_t* slot_material;
+  const int32_t* slot_prim; /* build-list primitive index, -1 for padding */
+  /* floor triangles tested before the tree (ganesha Floor): appended after the tree slots
+   * in tri / tri_uv / slot_* at indices n_slots .. n_slots + n_floor - 1 */
+  int32_t n_floor;
+  int32_t has_triangles;
+  int32_t has_emit;
+  int32_t has_checker;
+  const PtMaterial* materials;
+  const PtTexture* textures;
+  double cam_llx, cam_lly, cam_vx, cam_vy;
+  int32_t bg_kind;
+  int32_t pad0;
+  double bg_horizon[3];
+  double bg_zenith[3];
+};
+
+#endif /* PT_SCENE_H */

@@ -1,0 +1,249 @@
+"""GPU parity tests: the HIP path (through the C ABI, libptx_hip.so) against the CPU oracle.
+
+Bars: bit-exact for everything integer or per-sample (hit indices, work counters, per-sample radiance,
+raw per-pixel sums); <= 1e-5 relative L-inf for the filtered post-gamma
+framebuffer, where only the f64 summation order differs.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+REL_TOL = 1e-5  # north_star tolerance: max |gpu - cpu| / max(|cpu|, 1e-3)
+
+
+def rel_linf(gpu, cpu):
+    return float((np.abs(gpu - cpu) / np.maximum(np.abs(cpu), 1e-3)).max())
+
+
+def bits(a):
+    return np.ascontiguousarray(a, dtype=np.float64).view(np.uint64)
+
+
+@pytest.fixture(scope="module")
+def P():
+    import path_tracer_ocaml_amd as P
+    assert P.lib().ptx_device_count() >= 1, P.last_error()
+    return P
+
+
+@pytest.fixture(scope="module")
+def shirley(P, oracle):
+    d = oracle.desc_shirley(600, 300)
+    return d, oracle.Scene(d.ptr, d), P.Scene(d.ptr, 0, keepalive=d)
+
+
+# ---------------------------------------------------------------- shared math: device == host, bit for bit
+@pytest.mark.parametrize("fn", ["hypot", "sin", "cos", "acos", "atan2", "pow5", "sqrt", "div", "fma"])
+def test_math_device_equals_host_bitwise(P, oracle, fn):
+    rng = np.random.default_rng(hash(fn) % 2**32)
+    n = 1 << 20
+    if fn in ("sin", "cos"):
+        a = np.concatenate([rng.uniform(0, 2 * np.pi, n // 2), rng.uniform(-1e5, 1e5, n // 2)])
+        b = None
+    elif fn == "acos":
+        a = np.concatenate([rng.uniform(-1, 1, n - 4), [1.0, -1.0, 0.0, 0.5]])
+        b = None
+    elif fn == "pow5":
+        a = np.concatenate([rng.uniform(0, 1, n // 2), rng.uniform(-2, 2, n // 2)])
+        b = None
+    elif fn == "sqrt":
+        a = np.concatenate([rng.uniform(0, 4, n // 2), 10.0 ** rng.uniform(-300, 300, n // 2)])
+        b = None
+    else:
+        a = rng.uniform(-4, 4, n) * 10.0 ** rng.integers(-3, 4, n)
+        b = rng.uniform(-4, 4, n) * 10.0 ** rng.integers(-3, 4, n)
+    dev = P.math_eval(fn, a, b)
+    host = oracle.math_vec(P.MATH_FN[fn], a, b)
+    same = bits(dev) == bits(host)
+    both_nan = np.isnan(dev) & np.isnan(host)
+    assert (same | both_nan).all(), f"{fn}: {(~(same | both_nan)).sum()} of {n} results differ between gfx950 and x86-64"
+
+
+def test_lds_sample_bitwise(P, oracle):
+    rng = np.random.default_rng(1)
+    for dim in (2, 18, 34):
+        off = rng.integers(0, 8_359_679, 100_000).astype(np.int32)
+        dims = rng.integers(0, dim, 100_000).astype(np.int32)
+        dev = P.lds_sample(dim, off, dims)
+        assert np.array_equal(bits(dev), bits(oracle.lds_get_vec(dim, off, dims)))
+
+
+# ---------------------------------------------------------------- traverse + intersect
+def _camera_rays(oracle, d, n, seed):
+    rng = np.random.default_rng(seed)
+    cam = d.arrays()["camera"]
+    dirs = np.zeros((n, 3))
+    cx, cy = rng.random(n), rng.random(n)
+    v = np.stack([cam[0] + cam[2] * cx, cam[1] + cam[3] * cy, -np.ones(n)], axis=1)
+    dirs = v / np.linalg.norm(v, axis=1, keepdims=True)
+    return np.zeros((n, 3)), dirs
+
+
+def _check_intersect(oracle, P, d, n=50_000, seed=0):
+    o_scene = oracle.Scene(d.ptr, d)
+    g_scene = P.Scene(d.ptr, 0, keepalive=d)
+    org, dirs = _camera_rays(oracle, d, n, seed)
+    # secondary-like rays: start on a sphere of hits, random directions
+    rng = np.random.default_rng(seed + 1)
+    t0, p0, _ = o_scene.intersect_rays(org, dirs)
+    hit = p0 >= 0
+    pts = org[hit] + dirs[hit] * t0[hit, None]
+    rd = rng.normal(size=pts.shape)
+    rd /= np.linalg.norm(rd, axis=1, keepdims=True)
+    org2 = np.concatenate([org, pts + 1e-3 * rd])
+    dirs2 = np.concatenate([dirs, rd])
+    t_c, p_c, ct_c = o_scene.intersect_rays(org2, dirs2)
+    t_g, p_g, st = g_scene.intersect_rays(org2, dirs2)
+    assert np.array_equal(p_g, p_c), f"{(p_g != p_c).sum()} hit primitives differ"
+    assert np.array_equal(bits(t_g), bits(t_c)), "t_hit differs"
+    assert st["segments"] == ct_c["segments"]
+    assert st["nodes_tested"] == ct_c["nodes_tested"], (st["nodes_tested"], ct_c["nodes_tested"])
+    assert st["prims_tested"] == ct_c["prims_tested"], (st["prims_tested"], ct_c["prims_tested"])
+    assert st["floor_tested"] == ct_c["floor_tested"]
+    assert (p_c >= 0).mean() > 0.3
+    g_scene.close()
+
+
+def test_intersect_rays_shirley_simd_leaf(P, oracle):
+    _check_intersect(oracle, P, oracle.desc_shirley(600, 300))
+
+
+def test_intersect_rays_shirley_array_leaf(P, oracle):
+    _check_intersect(oracle, P, oracle.desc_shirley(600, 300, no_simd=True))
+
+
+def test_intersect_rays_cornell_mixed_leaf(P, oracle):
+    _check_intersect(oracle, P, oracle.desc_cornell(256, 256))
+
+
+def test_intersect_rays_ganesha_like_with_floor(P, oracle):
+    _check_intersect(oracle, P, oracle.desc_ganesha_like(192, 108, n_target=20000), n=20_000)
+
+
+# ---------------------------------------------------------------- per-sample radiance: bit-exact
+def _check_samples(oracle, P, d, w, h, spp, depth, n=20_000, seed=3):
+    o_scene = oracle.Scene(d.ptr, d)
+    g_scene = P.Scene(d.ptr, 0, keepalive=d)
+    rng = np.random.default_rng(seed)
+    xs, ys, ps = rng.integers(0, w, n), rng.integers(0, h, n), rng.integers(0, spp, n)
+    c_rgb, c_ct = o_scene.trace_samples(w, h, spp, depth, xs, ys, ps)
+    g_rgb, g_st = g_scene.trace_samples(w, h, spp, depth, xs, ys, ps, count_work=True)
+    nbad = int((bits(g_rgb) != bits(c_rgb)).any(axis=1).sum())
+    assert nbad == 0, f"{nbad} of {n} samples differ from the oracle"
+    for k in ("segments", "nodes_tested", "prims_tested", "floor_tested"):
+        assert g_st[k] == c_ct[k], (k, g_st[k], c_ct[k])
+    g_scene.close()
+    return c_rgb
+
+
+def test_samples_shirley_config1(P, oracle):
+    rgb = _check_samples(oracle, P, oracle.desc_shirley(600, 300), 600, 300, 32, 8)
+    assert rgb.max() > 0.5 and (rgb == 0).all(axis=1).mean() < 0.9
+
+
+def test_samples_shirley_array_leaf(P, oracle):
+    _check_samples(oracle, P, oracle.desc_shirley(600, 300, no_simd=True), 600, 300, 32, 8)
+
+
+def test_samples_shirley_deep_and_shallow(P, oracle):
+    d = oracle.desc_shirley(320, 200)
+    _check_samples(oracle, P, d, 320, 200, 4, 1, n=5000)
+    _check_samples(oracle, P, d, 320, 200, 4, 16, n=5000)
+    _check_samples(oracle, P, d, 320, 200, 4, 0, n=100)
+
+
+def test_samples_cornell_with_emitter(P, oracle):
+    rgb = _check_samples(oracle, P, oracle.desc_cornell(256, 256), 256, 256, 16, 16)
+    assert rgb.max() > 0.0
+
+
+def test_samples_ganesha_like(P, oracle):
+    _check_samples(oracle, P, oracle.desc_ganesha_like(192, 108, n_target=20000), 192, 108, 8, 8)
+
+
+# ---------------------------------------------------------------- whole render
+def test_render_matches_oracle_and_golden(P, oracle, shirley):
+    d, o_scene, g_scene = shirley
+    import os
+    from PIL import Image
+    g_rgb, st = g_scene.render(600, 300, 32, 8, count_work=True)
+    c = o_scene.render(600, 300, 32, 8, threads=min(16, os.cpu_count() or 1), count=True)
+    assert rel_linf(g_rgb, c["rgb"]) <= REL_TOL
+    # far tighter in practice: only the f64 summation order differs
+    assert rel_linf(g_rgb, c["rgb"]) <= 1e-12
+    for k in ("samples", "segments", "nodes_tested", "prims_tested"):
+        assert st[k] == c["counters"][k], (k, st[k], c["counters"][k])
+    golden = np.array(Image.open(os.path.join(os.path.dirname(__file__), "golden", "shirley-spheres.png")).convert("RGB"))
+    mine = np.clip(g_rgb * 255.0, 0, 255).astype(np.int64)
+    ndiff = int((mine != golden).sum())
+    # a value within 1e-13 of an integer boundary could flip one byte; the oracle itself has 0
+    assert ndiff <= 2, f"{ndiff} bytes differ from the reference's golden PNG"
+
+
+def test_raw_sums_bitwise_and_band_sharding(P, oracle):
+    torch = pytest.importorskip("torch")
+    w, h, spp, depth = 200, 150, 6, 8
+    d = oracle.desc_shirley(w, h)
+    o_scene = oracle.Scene(d.ptr, d)
+    g_scene = P.Scene(d.ptr, 0, keepalive=d)
+    c = o_scene.render(w, h, spp, depth, threads=8, want_raw=True)
+    # whole image on one rank, two batches of passes
+    params = P.render_params(w, h, spp, depth, passes_per_batch=4)
+    raw = torch.zeros((h, w, 3), dtype=torch.float64, device="cuda:0")
+    g_scene.render_raw_device(params, raw.data_ptr())
+    assert np.array_equal(bits(raw.cpu().numpy()), bits(c["raw"])), "raw per-pixel sums differ from the oracle"
+    # 3 ranks, interleaved bands of 32 rows (ragged: 150 = 4*32 + 22)
+    full = torch.zeros((h, w, 3), dtype=torch.float64, device="cuda:0")
+    seen = np.zeros(h, dtype=int)
+    for rank in range(3):
+        pr = P.render_params(w, h, spp, depth, band_rows=32, band_first=rank, band_step=3)
+        rows = P.local_rows(pr)
+        part = torch.zeros((rows, w, 3), dtype=torch.float64, device="cuda:0")
+        g_scene.render_raw_device(pr, part.data_ptr())
+        for k in range(rows):
+            gy = P.global_row(pr, k)
+            full[gy] = part[k]
+            seen[gy] += 1
+    assert (seen == 1).all()
+    assert np.array_equal(bits(full.cpu().numpy()), bits(c["raw"]))
+    # film on the device == oracle framebuffer within tolerance
+    out = torch.zeros((h, w, 3), dtype=torch.float64, device="cuda:0")
+    P.film_resolve_device(0, w, h, spp, full.data_ptr(), out.data_ptr())
+    assert rel_linf(out.cpu().numpy(), c["rgb"]) <= 1e-12
+    g_scene.close()
+
+
+def test_render_cornell_and_ganesha_like(P, oracle):
+    for d, w, h, spp, depth in [(oracle.desc_cornell(128, 128), 128, 128, 16, 16),
+                                (oracle.desc_ganesha_like(160, 90, n_target=20000), 160, 90, 8, 8)]:
+        o_scene = oracle.Scene(d.ptr, d)
+        g_scene = P.Scene(d.ptr, 0, keepalive=d)
+        g_rgb, _ = g_scene.render(w, h, spp, depth)
+        c = o_scene.render(w, h, spp, depth, threads=8)
+        assert c["rgb"].max() > 0.05
+        assert rel_linf(g_rgb, c["rgb"]) <= 1e-12
+        g_scene.close()
+
+
+def test_ragged_and_tiny_images(P, oracle):
+    for w, h in [(1, 1), (7, 5), (33, 9), (65, 3)]:
+        d = oracle.desc_shirley(w, h)
+        o_scene = oracle.Scene(d.ptr, d)
+        g_scene = P.Scene(d.ptr, 0, keepalive=d)
+        g_rgb, _ = g_scene.render(w, h, 3, 4)
+        c = o_scene.render(w, h, 3, 4)
+        assert rel_linf(g_rgb, c["rgb"]) <= 1e-12
+        g_scene.close()
+
+
+def test_error_paths(P, oracle):
+    d = oracle.desc_shirley(8, 8)
+    g_scene = P.Scene(d.ptr, 0, keepalive=d)
+    with pytest.raises(P.PtxError):
+        g_scene.render(0, 8, 1, 1)
+    with pytest.raises(P.PtxError):
+        g_scene.render(8, 8, 0, 1)
+    with pytest.raises(P.PtxError):
+        g_scene.trace_samples(8, 8, 1, 1, [9], [0], [0])
+    g_scene.close()
