@@ -1743,4 +1743,41 @@ ORC_API int orc_render(const orc_scene* sc, int width, int height, int spp, int 
   return 0;
 }
 
+/* parity aid: state after the first segment of each sample (mirror of ptx_debug_first_scatter) */
+ORC_API void orc_debug_first_scatter(const orc_scene* sc, int width, int height, int spp, int max_bounces, int64_t n,
+                                     const int32_t* xs, const int32_t* ys, const int32_t* passes, double* ray_out, double* attn_out, int32_t* alive_out, int32_t* info_out) {
+  int dim = 2 + 2 * max_bounces;
+  double* alpha = (double*)malloc(sizeof(double) * (size_t)dim);
+  orc_lds_alpha(dim, alpha);
+  double widthf = 1.0 / (double)width, heightf = 1.0 / (double)height;
+  for (int64_t i = 0; i < n; ++i) {
+    sampler_t smp; smp.alpha = alpha; smp.offset = (ys[i] * width) + xs[i] + (passes[i] * spp);
+    double dx = sample_dim(&smp, 0), dy = sample_dim(&smp, 1);
+    double cx = ((double)xs[i] + dx) * widthf, cy = 1.0 - (((double)ys[i] + dy) * heightf);
+    ray_t ray = camera_ray(&sc->camera, cx, cy);
+    alive_out[i] = 0;
+    hit_t h; int prim = -1;
+    if (info_out) { info_out[3 * i] = -1; info_out[3 * i + 1] = -1; info_out[3 * i + 2] = -1; }
+    if (!scene_intersect(sc, &ray, &h, NULL, &prim, NULL)) continue;
+    double u = sample_dim(&smp, 2), v = sample_dim(&smp, 3);
+    scatter_t s = hit_scatter(&sc->mt, &h, u);
+    if (info_out) { info_out[3 * i] = prim; info_out[3 * i + 1] = h.m->kind; info_out[3 * i + 2] = s.kind; }
+    ray_t out; v3 att;
+    if (s.kind == SC_ABSORB) continue;
+    if (s.kind == SC_SPECULAR) { out = s.ray; att = s.attenuation; }
+    else {
+      v3 dir = unit_square_to_hemisphere(u, v);
+      double pd = pdf_eval_diffuse(dir);
+      if (pd == 0.0) continue;
+      out = sspace_world_ray(&h.shader_space, dir);
+      att = v3_scale(s.attenuation, pd / pd);
+    }
+    alive_out[i] = 1;
+    ray_out[6 * i] = out.origin.x; ray_out[6 * i + 1] = out.origin.y; ray_out[6 * i + 2] = out.origin.z;
+    ray_out[6 * i + 3] = out.direction.x; ray_out[6 * i + 4] = out.direction.y; ray_out[6 * i + 5] = out.direction.z;
+    attn_out[3 * i] = att.x; attn_out[3 * i + 1] = att.y; attn_out[3 * i + 2] = att.z;
+  }
+  free(alpha);
+}
+
 ORC_API int orc_abi_version(void) { return PTX_ABI_VERSION; }

@@ -45,6 +45,13 @@ def lib():
     if not os.path.exists(LIB_PATH):
         raise PtxError(f"{LIB_PATH} is missing: build it with `make -C {os.path.join(_HERE, 'csrc')}` "
                        "(python -c 'import __graft_entry__ as g; g.build()'). There is no CPU fallback.")
+    # PyTorch bundles its own libamdhip64.so.7.  Two HIP runtimes in one process cannot both own the GPU
+    # ("No HIP GPUs are available" from whichever initialises second), so when torch is installed load it
+    # FIRST: libptx_hip.so's DT_NEEDED libamdhip64.so.7 then binds to the copy that is already mapped.
+    try:
+        import torch  # noqa: F401
+    except Exception:  # torch is optional: the C ABI does not need it
+        pass
     L = C.CDLL(LIB_PATH)
     L.ptx_version.restype = C.c_int32
     L.ptx_leaf_size.restype = C.c_int32

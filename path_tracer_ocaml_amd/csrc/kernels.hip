@@ -549,15 +549,17 @@ __global__ __launch_bounds__(256) void k_shade(PtSceneDev sc, PtQueue q, PtHits 
           const double c = wi_z < 0.0 ? 0.0 : (1.0 < wi_z ? 1.0 : wi_z); /* Float.clamp_exn */
           const double sn = pt_sqrt(1.0 - c * c);
           const double refract_ratio = hit_front ? index_inv : index;
-          if (refract_ratio * sn > 1.0 || pt_schlick(c, refract_ratio) > su) {
-            wo = v3(-omega_i.x, -omega_i.y, omega_i.z);
-          } else {
-            /* Shader_space.refract (shader_space.ml:41-49) */
-            const double cc = pt_base_min(omega_i.z, 1.0);
-            const V3 perp = v3_scale(v3_sub(v3(0.0, 0.0, cc), omega_i), refract_ratio);
-            const V3 para = v3(0.0, 0.0, -pt_sqrt(pt_fabs(1.0 - v3_quadrance(perp))));
-            wo = v3_add(perp, para);
-          }
+          /* both candidate directions are cheap; evaluate them unconditionally and select, so the wave
+           * does not diverge on the reflect / refract decision */
+          const bool reflect = (refract_ratio * sn > 1.0) || (pt_schlick(c, refract_ratio) > su);
+          /* Shader_space.refract (shader_space.ml:41-49) */
+          const double cc = pt_base_min(omega_i.z, 1.0);
+          const V3 perp = v3_scale(v3_sub(v3(0.0, 0.0, cc), omega_i), refract_ratio);
+          const V3 para = v3(0.0, 0.0, -pt_sqrt(pt_fabs(1.0 - v3_quadrance(perp))));
+          const V3 refr = v3_add(perp, para);
+          wo.x = reflect ? -omega_i.x : refr.x; /* Shader_space.reflect (shader_space.ml:34-39) */
+          wo.y = reflect ? -omega_i.y : refr.y;
+          wo.z = reflect ? omega_i.z : refr.z;
         }
 
         if (sc_kind == 0) {
