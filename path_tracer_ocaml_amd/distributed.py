@@ -1,0 +1,59 @@
+"""Image-band sharding across ranks (one process per GPU) and the single exchange step of the path:
+gathering every rank's raw per-pixel sums to rank 0 (RCCL over xGMI: torch.distributed backend "nccl";
+"gloo" on CPU for tests).
+
+The reference parallelises over image tiles inside one process (Domainslib pool, integrator.ml:136-151);
+across GPUs the unit is a horizontal BAND of `band_rows` image rows, dealt round-robin (band k -> rank
+k mod world) so that cheap sky rows and expensive ground rows are spread evenly.  Samples are independent and
+the sampler offset depends only on the GLOBAL (x, y, pass) (integrator.ml:98), so the partition does not
+change any value: rank 0 reassembles bit-identical raw sums, then runs the film filter once.
+"""
+import numpy as np
+
+BAND_ROWS = 32
+
+
+def band_layout(height, world, band_rows=BAND_ROWS):
+    """rows[r] = global image rows owned by rank r, in the order ptx_render_raw_device stores them."""
+    n_bands = (height + band_rows - 1) // band_rows
+    rows = []
+    for r in range(world):
+        mine = []
+        for b in range(r, n_bands, world):
+            mine.extend(range(b * band_rows, min((b + 1) * band_rows, height)))
+        rows.append(np.asarray(mine, dtype=np.int64))
+    return rows
+
+
+def max_local_rows(height, world, band_rows=BAND_ROWS):
+    return max(len(r) for r in band_layout(height, world, band_rows))
+
+
+def gather_raw_to_root(part, height, width, rank, world, band_rows=BAND_ROWS, group=None):
+    """part: this rank's (local_rows, W, 3) f64 tensor.  Returns the full (H, W, 3) tensor on rank 0, None elsewhere.
+
+    One collective: torch.distributed.gather of equal-size (padded) chunks; on MI355X each peer's chunk
+    travels over its own xGMI link into the root."""
+    import torch
+    import torch.distributed as dist
+
+    layout = band_layout(height, world, band_rows)
+    if world == 1:
+        full = torch.empty((height, width, 3), dtype=part.dtype, device=part.device)
+        full[torch.as_tensor(layout[0], device=part.device)] = part
+        return full
+    pad = max(len(r) for r in layout)
+    send = part
+    if part.shape[0] != pad:
+        send = torch.zeros((pad, width, 3), dtype=part.dtype, device=part.device)
+        send[: part.shape[0]] = part
+    send = send.contiguous()
+    bufs = [torch.empty_like(send) for _ in range(world)] if rank == 0 else None
+    dist.gather(send, gather_list=bufs, dst=0, group=group)
+    if rank != 0:
+        return None
+    full = torch.empty((height, width, 3), dtype=part.dtype, device=part.device)
+    for r in range(world):
+        idx = torch.as_tensor(layout[r], device=part.device)
+        full[idx] = bufs[r][: len(layout[r])]
+    return full

@@ -1,0 +1,103 @@
+"""The product's host-side scene mirrors (C++, libpt_host.so) and host BVH builder (libptx_hip.so, host-only
+scenes) against the oracle's independent restatement: every array bit-identical, every tree identical."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+
+def _same(a, b):
+    assert a.keys() == b.keys()
+    for k in a:
+        x, y = np.asarray(a[k]), np.asarray(b[k])
+        assert x.shape == y.shape, k
+        if x.dtype.kind == "f":
+            assert np.array_equal(x.view(np.uint64), y.view(np.uint64)), f"{k} differs"
+        else:
+            assert np.array_equal(x, y), f"{k} differs"
+
+
+CASES = [
+    ("shirley", lambda H, O: (H.shirley_spheres(600, 300), O.desc_shirley(600, 300))),
+    ("shirley_no_simd", lambda H, O: (H.shirley_spheres(1920, 1080, no_simd=True), O.desc_shirley(1920, 1080, no_simd=True))),
+    ("cornell", lambda H, O: (H.cornell_box(1024, 1024, 12.0), O.desc_cornell(1024, 1024, 12.0))),
+    ("ganesha_like", lambda H, O: (H.ganesha_like(192, 108, 20000, 7), O.desc_ganesha_like(192, 108, 20000, 7))),
+]
+
+
+@pytest.mark.parametrize("name,make", CASES, ids=[c[0] for c in CASES])
+def test_host_scene_equals_oracle_scene(oracle, name, make):
+    from path_tracer_ocaml_amd import host as H
+    hs, od = make(H, oracle)
+    _same(hs.arrays(), od.arrays())
+
+
+@pytest.mark.parametrize("name,make", CASES, ids=[c[0] for c in CASES])
+def test_host_bvh_equals_oracle_bvh(oracle, name, make):
+    """Shape_tree.create restated twice (recursive/boxed in the oracle, index-permutation in the product)."""
+    import path_tracer_ocaml_amd as P
+    from path_tracer_ocaml_amd import host as H
+    hs, od = make(H, oracle)
+    prod = P.Scene(hs.ptr, device=-1, keepalive=hs)  # host-only: build + flatten, nothing uploaded
+    orc = oracle.Scene(od.ptr, od)
+    pb, pi, po = prod.tree()
+    ob, oi, oo = orc.tree()
+    assert np.array_equal(pb.view(np.uint64), ob.view(np.uint64))
+    assert np.array_equal(pi, oi)
+    assert np.array_equal(po, oo)
+    st, inf = prod.stats(), orc.info()
+    assert (st["tree_nodes"], st["tree_depth"], st["tree_leaves"], st["leaf_slots"]) == (inf["nodes"], inf["depth"], inf["leaves"], inf["slots"])
+
+
+def test_ganesha_like_full_size_tree(oracle):
+    """BASELINE config 4 size (~150 k triangles): same tree from both builders."""
+    import path_tracer_ocaml_amd as P
+    from path_tracer_ocaml_amd import host as H
+    hs = H.ganesha_like(1920, 1080, 150000, 7)
+    od = oracle.desc_ganesha_like(1920, 1080, 150000, 7)
+    assert 140000 < hs.d.n_triangles < 160000
+    prod = P.Scene(hs.ptr, device=-1, keepalive=hs)
+    pb, pi, po = prod.tree()
+    ob, oi, oo = oracle.Scene(od.ptr, od).tree()
+    assert np.array_equal(pb.view(np.uint64), ob.view(np.uint64)) and np.array_equal(pi, oi) and np.array_equal(po, oo)
+
+
+def test_camera_mirror(oracle):
+    from path_tracer_ocaml_amd import abi, host as H
+    eye, tgt, up = np.array([13.0, 2.0, 4.5]), np.zeros(3), np.array([0.0, 1.0, 0.0])
+    view = abi.Camera()
+    la = np.zeros(16)
+    dp = abi.c_double_p
+    H.lib().pth_camera_create(eye.ctypes.data_as(dp), tgt.ctypes.data_as(dp), up.ctypes.data_as(dp), 2.0, 20.0,
+                              C.byref(view), la.ctypes.data_as(dp))
+    cam = np.zeros(4)
+    ola = np.zeros(16)
+    oracle.lib().orc_camera_create(eye.ctypes.data_as(dp), tgt.ctypes.data_as(dp), up.ctypes.data_as(dp), 2.0, 20.0,
+                                   cam.ctypes.data_as(dp), ola.ctypes.data_as(dp))
+    assert [view.lower_left_x, view.lower_left_y, view.view_x, view.view_y] == list(cam)
+    assert np.array_equal(la.view(np.uint64), ola.view(np.uint64))
+
+
+def test_png_writer_roundtrip(tmp_path):
+    from PIL import Image
+    from path_tracer_ocaml_amd import host as H
+    rng = np.random.default_rng(0)
+    rgb = rng.random((37, 53, 3)) * 1.2 - 0.1
+    path = str(tmp_path / "t.png")
+    H.write_png(path, rgb)
+    got = np.array(Image.open(path).convert("RGB"))
+    want = np.clip(rgb * 255.0, 0, 255).astype(np.uint8)
+    assert np.array_equal(got, want)
+
+
+def test_png_writer_reproduces_golden(oracle, tmp_path):
+    """oracle framebuffer -> the product's PNG writer == the reference's shirley-spheres.png, byte for byte."""
+    from PIL import Image
+    from path_tracer_ocaml_amd import host as H
+    d = oracle.desc_shirley(600, 300)
+    rgb = oracle.Scene(d.ptr, d).render(600, 300, 32, 8, threads=min(8, os.cpu_count() or 1))["rgb"]
+    path = str(tmp_path / "s.png")
+    H.write_png(path, rgb)
+    golden = np.array(Image.open(os.path.join(os.path.dirname(__file__), "golden", "shirley-spheres.png")).convert("RGB"))
+    assert np.array_equal(np.array(Image.open(path).convert("RGB")), golden)
