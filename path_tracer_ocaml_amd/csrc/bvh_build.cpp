@@ -164,6 +164,7 @@ class Builder {
     if (pad4_) len = (n + 3) & ~3;
     node.a = (uint32_t)out_.slot_prim.size();
     node.b = (uint32_t)len | (PT_NODE_LEAF_AXIS << 30);
+    node.pad[0] = (uint32_t)n; /* real elements: the NaN padding slots can never be selected */
     for (int k = 0; k < len; ++k) out_.slot_prim.push_back(k < n ? order_[lo + k] : -1);
     out_.nodes.push_back(node);
     out_.leaves++;

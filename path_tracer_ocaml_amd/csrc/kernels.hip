@@ -14,6 +14,8 @@
  */
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "pt_scene.h"
 #include "pt_vec.h"
 
@@ -88,37 +90,6 @@ __device__ __forceinline__ int pt_global_row(const PtGenParams& g, int local_row
 /* Camera.ray (camera.ml:93-102): direction only; the origin is P3.origin */
 __device__ __forceinline__ V3 pt_camera_dir(const PtSceneDev& sc, double cx, double cy) {
   return v3_normalize(v3(sc.cam_llx + (sc.cam_vx * cx), sc.cam_lly + (sc.cam_vy * cy), -1.0));
-}
-
-/* One thread per (pass, pixel); a wave covers one 8x8 pixel tile so primary rays stay coherent. */
-__global__ __launch_bounds__(256) void k_generate(PtSceneDev sc, PtGenParams g, const double* __restrict__ alpha,
-                                                  PtQueue q) {
-  const long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  const long long per_pass = (long long)g.tiles_x * g.tiles_y * 64;
-  const int pass_in_batch = (int)(tid / per_pass);
-  const long long rem = tid - (long long)pass_in_batch * per_pass;
-  const int tile = (int)(rem >> 6);
-  const int lane = (int)(rem & 63);
-  const int tx = tile % g.tiles_x, ty = tile / g.tiles_x;
-  const int x = tx * 8 + (lane & 7), y = ty * 8 + (lane >> 3);
-  const bool valid = pass_in_batch < g.n_pass && x < g.width && y < g.local_rows;
-  const uint32_t dst = pt_wave_append(q.count, valid);
-  if (!valid) return;
-  const int gy = pt_global_row(g, y);
-  const int pass = g.first_pass + pass_in_batch;
-  /* render_tile, integrator.ml:98-105 */
-  const int offset = (gy * g.width) + x + (pass * g.spp);
-  const double widthf = 1.0 / (double)g.width, heightf = 1.0 / (double)g.height;
-  const double dxs = pt_lds_get(alpha, offset, 0), dys = pt_lds_get(alpha, offset, 1);
-  const double cx = ((double)x + dxs) * widthf;
-  const double cy = 1.0 - (((double)gy + dys) * heightf);
-  const V3 dir = pt_camera_dir(sc, cx, cy);
-  q.ox[dst] = 0.0; q.oy[dst] = 0.0; q.oz[dst] = 0.0;
-  q.dx[dst] = dir.x; q.dy[dst] = dir.y; q.dz[dst] = dir.z;
-  q.ar[dst] = 1.0; q.ag[dst] = 1.0; q.ab[dst] = 1.0; /* Color.white */
-  if (sc.has_emit) { q.er[dst] = 0.0; q.eg[dst] = 0.0; q.eb[dst] = 0.0; } /* Color.black */
-  q.id[dst] = (uint32_t)((long long)pass_in_batch * g.width * g.local_rows + (long long)y * g.width + x);
-  q.offset[dst] = offset;
 }
 
 /* explicit (x, y, pass) triples: ptx_trace_samples */
@@ -205,19 +176,270 @@ __device__ __forceinline__ bool pt_sphere_intersect_scalar(V3 center, double rad
   return false;
 }
 
-/* One lane = one ray.  The traversal stack (far children only) lives in LDS, one column per lane,
- * so pushes/pops are conflict-free ds_write_b32 / ds_read_b32.  A far child's bbox is tested when it
+/* Decodes entry i of a PRIMARY (bounce 0) launch: the queue is virtual -- entry i IS sample
+ * (pass_in_batch, tile, lane) -- so camera rays are never written to or read from HBM. */
+struct PtPrimarySample {
+  int x, y, gy, pass_in_batch, offset;
+  uint32_t id;
+  bool valid;
+};
+__device__ __forceinline__ PtPrimarySample pt_primary_decode(const PtGenParams& g, uint32_t i) {
+  PtPrimarySample s;
+  const uint32_t per_pass = (uint32_t)(g.tiles_x * g.tiles_y) * 64u;
+  const uint32_t pass_in_batch = i / per_pass;
+  const uint32_t rem = i - pass_in_batch * per_pass;
+  const int tile = (int)(rem >> 6), lane = (int)(rem & 63);
+  const int ty = tile / g.tiles_x, tx = tile - ty * g.tiles_x;
+  s.x = tx * 8 + (lane & 7);
+  s.y = ty * 8 + (lane >> 3);
+  s.pass_in_batch = (int)pass_in_batch;
+  s.valid = (int)pass_in_batch < g.n_pass && s.x < g.width && s.y < g.local_rows;
+  s.gy = pt_global_row(g, s.y);
+  s.offset = (s.gy * g.width) + s.x + ((g.first_pass + (int)pass_in_batch) * g.spp); /* integrator.ml:98 */
+  s.id = (uint32_t)((long long)pass_in_batch * g.width * g.local_rows + (long long)s.y * g.width + s.x);
+  return s;
+}
+/* render_tile (integrator.ml:98-105) + Camera.ray (camera.ml:93-102) */
+__device__ __forceinline__ V3 pt_primary_dir(const PtSceneDev& sc, const PtGenParams& g, const PtPrimarySample& s,
+                                             const double* __restrict__ alpha) {
+  const double widthf = 1.0 / (double)g.width, heightf = 1.0 / (double)g.height;
+  const double dxs = pt_lds_get(alpha, s.offset, 0), dys = pt_lds_get(alpha, s.offset, 1);
+  const double cx = ((double)s.x + dxs) * widthf;
+  const double cy = 1.0 - (((double)s.gy + dys) * heightf);
+  return pt_camera_dir(sc, cx, cy);
+}
+
+/* Bbox.is_hit when no 0 * inf can occur (every 1/d component finite): no NaN is ever produced, so Base's
+ * NaN-propagating min/max coincide with the hardware v_min_f64 / v_max_f64 -- same boolean, 4x fewer
+ * instructions.  (The values may differ in the sign of a zero, which no comparison can see.) */
+__device__ __forceinline__ bool pt_slab_hit_fast(const double* nb, V3 o, V3 inv, double t_min, double t_max) {
+  const double t0x = (nb[0] - o.x) * inv.x, t0y = (nb[1] - o.y) * inv.y, t0z = (nb[2] - o.z) * inv.z;
+  const double t1x = (nb[3] - o.x) * inv.x, t1y = (nb[4] - o.y) * inv.y, t1z = (nb[5] - o.z) * inv.z;
+  const double a = __builtin_fmax(__builtin_fmin(t0x, t1x), __builtin_fmax(__builtin_fmin(t0y, t1y), __builtin_fmin(t0z, t1z)));
+  const double b = __builtin_fmin(__builtin_fmax(t0x, t1x), __builtin_fmin(__builtin_fmax(t0y, t1y), __builtin_fmax(t0z, t1z)));
+  return __builtin_fmax(t_min, a) <= __builtin_fmin(t_max, b);
+}
+__device__ __forceinline__ bool pt_slab_hit_exact(const double* nb, V3 o, V3 inv, double t_min, double t_max) {
+  PtNode n;
+  n.mn[0] = nb[0]; n.mn[1] = nb[1]; n.mn[2] = nb[2];
+  n.mx[0] = nb[3]; n.mx[1] = nb[4]; n.mx[2] = nb[5];
+  return pt_slab_hit(n, o, inv, t_min, t_max);
+}
+
+/* where the traversal data of this launch lives: HBM/L2 (large scenes) or an LDS copy (small scenes) */
+struct PtSceneView {
+  const PtNode* nodes;
+  const double* sph;
+  const double* tri;
+  const uint8_t* kind;
+};
+
+struct PtTraceResult {
+  double t, u, v;
+  int slot;
+};
+
+/* Scene.intersect for ONE ray held by this lane.  The traversal stack (far children only) lives in LDS,
+ * one column per lane (conflict-free ds_write_b32 / ds_read_b32).  A far child's bbox is tested when it
  * is POPPED, against the closest hit so far -- exactly the t_max the reference's recursion passes
  * (shape_tree.ml:210-216). */
-template <int MODE, bool COUNT>
-__global__ __launch_bounds__(256) void k_trace(PtSceneDev sc, PtQueue q, PtHits hits, int stack_depth,
-                                               PtCounters* counters, const uint32_t* n_override) {
-  extern __shared__ uint32_t lds_stack[];
+#define PT_STACK_PUSH(stk, sp, val) ((stk)[(sp) * PT_WAVE] = (StackT)(val))
+#define PT_STACK_POP(stk, sp) ((uint32_t)(stk)[(sp) * PT_WAVE])
+
+template <int MODE, bool COUNT, typename StackT>
+__device__ __forceinline__ PtTraceResult pt_trace_ray(const PtSceneDev& sc, const PtSceneView& sv, StackT* stack,
+                                                      V3 o, V3 d, unsigned long long& c_nodes,
+                                                      unsigned long long& c_prims, unsigned long long& c_floor) {
+  const V3 inv = v3(1.0 / d.x, 1.0 / d.y, 1.0 / d.z); /* Ray.create, ray.ml:7-10 */
+  /* dirs, shape_tree.ml:201 */
+  const uint32_t dirs = (d.x >= 0.0 ? 1u : 0u) | (d.y >= 0.0 ? 2u : 0u) | (d.z >= 0.0 ? 4u : 0u);
+  const bool exact_slab = !(pt_isfinite(inv.x) && pt_isfinite(inv.y) && pt_isfinite(inv.z));
+  const double t_min = 0.0;
+  PtTraceResult r;
+  r.t = PT_MAX_FINITE;
+  r.slot = -1;
+  r.u = 0.0;
+  r.v = 0.0;
+
+  /* ganesha Floor.intersect (main.ml:247-256): f1 then f2, the first hit clips t_max for the tree */
+  if (MODE == PT_MODE_ARRAY && sc.n_floor > 0) {
+    for (int f = 0; f < sc.n_floor; ++f) {
+      const double* tv = sv.tri + (size_t)(sc.n_slots + f) * 10;
+      double t, u, v;
+      if (COUNT) c_floor++;
+      if (pt_triangle_intersect(pt_load_v3(tv), pt_load_v3(tv + 3), pt_load_v3(tv + 6), o, d, 0.0, PT_MAX_FINITE, &t,
+                                &u, &v)) {
+        r.t = t;
+        r.u = u;
+        r.v = v;
+        r.slot = sc.n_slots + f;
+        break;
+      }
+    }
+  }
+
+  /* packet constants of spheres_intersect_aux (lib.rs:115-117): a is the UNFUSED scalar dot */
+  double qa = 0.0, one_over_a = 0.0;
+  if (MODE == PT_MODE_SIMD) {
+    qa = d.x * d.x + d.y * d.y + d.z * d.z;
+    one_over_a = 1.0 / qa;
+  }
+  if (sc.n_nodes <= 0) return r;
+
+  /* "while-while" traversal: every lane walks nodes until it reaches a leaf (or runs out of nodes); only
+   * then do the lanes that hold a leaf test its packet TOGETHER.  Interleaving the two, as the recursive
+   * reference does, would run the packet loop for one or two lanes at a time.  The order of node tests and
+   * packet tests of each individual ray is unchanged. */
+  int sp = 0;
+  uint32_t node = 0;
+  bool walking = true;
+  int leaf_first = 0, leaf_n = 0;
+  while (walking || leaf_n > 0) {
+    while (walking && leaf_n == 0) {
+      const PtNode* np = sv.nodes + node;
+      if (COUNT) c_nodes++;
+      bool descend = false;
+      const bool hit = exact_slab ? pt_slab_hit_exact(np->mn, o, inv, t_min, r.t) : pt_slab_hit_fast(np->mn, o, inv, t_min, r.t);
+      if (hit) {
+        const uint32_t na = np->a, nb = np->b;
+        const uint32_t axis = nb >> 30;
+        if (axis == PT_NODE_LEAF_AXIS) {
+          leaf_first = (int)na;
+          leaf_n = (int)np->pad[0]; /* real slots; the NaN padding (main.ml:185) can never be selected */
+          if (COUNT) c_prims += (unsigned long long)(nb & 0x3fffffffu); /* Leaf.length incl. padding */
+        } else {
+          /* Branch: near child first (shape_tree.ml:209), far child deferred */
+          const uint32_t lhs = na, rhs = nb & 0x3fffffffu;
+          const bool lhs_first = (dirs >> axis) & 1u;
+          PT_STACK_PUSH(stack, sp, lhs_first ? rhs : lhs);
+          ++sp;
+          node = lhs_first ? lhs : rhs;
+          descend = true;
+        }
+      }
+      if (!descend) {
+        /* the popped node's bbox is tested on the NEXT visit, i.e. after this leaf's packet has been
+         * intersected and r.t shrunk -- the t_max the reference passes to the far child */
+        if (sp == 0) walking = false;
+        else {
+          --sp;
+          node = PT_STACK_POP(stack, sp);
+        }
+      }
+    }
+    if (leaf_n > 0) {
+      if (MODE == PT_MODE_SIMD) {
+        /* spheres_intersect_aux, lib.rs:102-178, one packet lane per iteration */
+        for (int k = 0; k < leaf_n; ++k) {
+          const double* s = sv.sph + (size_t)(leaf_first + k) * 4;
+          const double fx = s[0] - o.x, fy = s[1] - o.y, fz = s[2] - o.z;
+          const double r2 = s[3] * s[3];
+          const double c = pt_fma(fx, fx, pt_fma(fy, fy, fz * fz)) - r2;
+          const double bp = pt_fma(fx, d.x, pt_fma(fy, d.y, fz * d.z));
+          const double bp_over_a = bp * one_over_a;
+          const double wx = pt_fma(d.x, bp_over_a, -fx);
+          const double wy = pt_fma(d.y, bp_over_a, -fy);
+          const double wz = pt_fma(d.z, bp_over_a, -fz);
+          const double wq = pt_fma(wx, wx, pt_fma(wy, wy, wz * wz));
+          const double disc = r2 - wq;
+          /* lanes whose discriminant has its sign bit set (or is NaN) end up NaN: skip them */
+          if (disc == disc && !pt_signbit(disc)) {
+            const double q_rhs = pt_sqrt(qa * disc);
+            const double qq = pt_signbit(bp) ? (bp - q_rhs) : (bp + q_rhs);
+            const double t = pt_signbit(c) ? (qq * one_over_a) : (c / qq);
+            /* not (t < t_min), not (t > t_max), then `t <= t_found` (last index wins ties) */
+            if (!(t < t_min) && t <= r.t) {
+              r.t = t;
+              r.slot = leaf_first + k;
+            }
+          }
+        }
+      } else {
+        /* Array_leaf.intersect, shape_tree.ml:299-311: shrinking t_max, later element wins ties */
+        for (int k = 0; k < leaf_n; ++k) {
+          const int slot = leaf_first + k;
+          if (sv.kind[slot] == PT_SLOT_SPHERE) {
+            const double* s = sv.sph + (size_t)slot * 4;
+            double t;
+            if (pt_sphere_intersect_scalar(v3(s[0], s[1], s[2]), s[3], o, d, t_min, r.t, &t)) {
+              r.t = t;
+              r.slot = slot;
+            }
+          } else {
+            const double* tv = sv.tri + (size_t)slot * 10;
+            double t, u, v;
+            if (pt_triangle_intersect(pt_load_v3(tv), pt_load_v3(tv + 3), pt_load_v3(tv + 6), o, d, t_min, r.t, &t, &u,
+                                      &v)) {
+              r.t = t;
+              r.u = u;
+              r.v = v;
+              r.slot = slot;
+            }
+          }
+        }
+      }
+      leaf_n = 0;
+    }
+  }
+  return r;
+}
+
+/* The traverse + intersect stage.  PRIMARY: bounce 0, rays come from the sampler + camera, not from a queue.
+ * LDS_SCENE: the whole tree and every leaf packet are first copied into LDS (small scenes: Shirley is
+ * 22 KB of nodes + 22 KB of packets), so node / packet reads are ds_read_b128 instead of L1 traffic.
+ * LDS layout: [traversal stacks: waves x depth x 64 u32][nodes][sphere slots][triangle slots][slot kinds] */
+template <int MODE, bool COUNT, bool PRIMARY, bool LDS_SCENE>
+__global__ __launch_bounds__(LDS_SCENE ? 1024 : 512) void k_trace(PtSceneDev sc, PtQueue q, PtHits hits, int stack_depth,
+                                               PtCounters* counters, PtGenParams g, const double* __restrict__ alpha,
+                                               uint32_t n_primary) {
+  extern __shared__ __attribute__((aligned(64))) unsigned char lds_raw[];
   const int lane = pt_lane();
   const int wave_in_block = (int)(threadIdx.x >> 6);
-  uint32_t* stack = lds_stack + (size_t)wave_in_block * stack_depth * PT_WAVE + lane;
-  const uint32_t n = n_override ? *n_override : *q.count;
   const uint32_t waves_per_block = blockDim.x >> 6;
+  /* LDS-resident scenes have < 65536 nodes: 16-bit stack entries halve the stack footprint */
+  typedef typename std::conditional<LDS_SCENE, uint16_t, uint32_t>::type StackT;
+  StackT* stack = (StackT*)lds_raw + (size_t)wave_in_block * stack_depth * PT_WAVE + lane;
+  PtSceneView sv;
+  sv.nodes = sc.nodes;
+  sv.sph = sc.sph;
+  sv.tri = sc.tri;
+  sv.kind = sc.slot_kind;
+  if (LDS_SCENE) {
+    size_t off = ((size_t)waves_per_block * stack_depth * PT_WAVE * sizeof(StackT) + 63) & ~(size_t)63;
+    PtNode* l_nodes = (PtNode*)(lds_raw + off);
+    off += (size_t)sc.n_nodes * sizeof(PtNode);
+    const int total_slots = sc.n_slots + sc.n_floor;
+    double* l_sph = (double*)(lds_raw + off);
+    off += (size_t)total_slots * 4 * sizeof(double);
+    double* l_tri = (double*)(lds_raw + off);
+    if (MODE == PT_MODE_ARRAY && sc.has_triangles) off += (size_t)total_slots * 10 * sizeof(double);
+    uint8_t* l_kind = (uint8_t*)(lds_raw + off);
+    /* cooperative copy, 16 bytes per thread per step */
+    {
+      const uint4* src = (const uint4*)sc.nodes;
+      uint4* dst = (uint4*)l_nodes;
+      for (int k = threadIdx.x; k < sc.n_nodes * 4; k += blockDim.x) dst[k] = src[k];
+    }
+    {
+      const uint4* src = (const uint4*)sc.sph;
+      uint4* dst = (uint4*)l_sph;
+      for (int k = threadIdx.x; k < total_slots * 2; k += blockDim.x) dst[k] = src[k];
+    }
+    if (MODE == PT_MODE_ARRAY) {
+      if (sc.has_triangles) {
+        const uint4* src = (const uint4*)sc.tri;
+        uint4* dst = (uint4*)l_tri;
+        for (int k = threadIdx.x; k < total_slots * 5; k += blockDim.x) dst[k] = src[k];
+      }
+      for (int k = threadIdx.x; k < total_slots; k += blockDim.x) l_kind[k] = sc.slot_kind[k];
+    }
+    __syncthreads();
+    sv.nodes = l_nodes;
+    sv.sph = l_sph;
+    sv.tri = l_tri;
+    sv.kind = l_kind;
+  }
+  const uint32_t n = PRIMARY ? n_primary : *q.count;
   const uint32_t gwave = blockIdx.x * waves_per_block + wave_in_block;
   const uint32_t nwaves = gridDim.x * waves_per_block;
   unsigned long long c_nodes = 0, c_prims = 0, c_floor = 0, c_seg = 0;
@@ -225,132 +447,23 @@ __global__ __launch_bounds__(256) void k_trace(PtSceneDev sc, PtQueue q, PtHits 
   for (uint32_t chunk = gwave; (unsigned long long)chunk * PT_WAVE < n; chunk += nwaves) {
     const uint32_t i = chunk * PT_WAVE + lane;
     if (i >= n) continue;
-    const V3 o = v3(q.ox[i], q.oy[i], q.oz[i]);
-    const V3 d = v3(q.dx[i], q.dy[i], q.dz[i]);
-    const V3 inv = v3(1.0 / d.x, 1.0 / d.y, 1.0 / d.z); /* Ray.create, ray.ml:7-10 */
-    /* dirs, shape_tree.ml:201 */
-    const uint32_t dirs = (d.x >= 0.0 ? 1u : 0u) | (d.y >= 0.0 ? 2u : 0u) | (d.z >= 0.0 ? 4u : 0u);
-    const double t_min = 0.0;
-    double t_best = PT_MAX_FINITE;
-    int slot_best = -1;
-    double u_best = 0.0, v_best = 0.0;
+    V3 o, d;
+    if (PRIMARY) {
+      const PtPrimarySample ps = pt_primary_decode(g, i);
+      if (!ps.valid) continue;
+      o = v3(0.0, 0.0, 0.0); /* P3.origin */
+      d = pt_primary_dir(sc, g, ps, alpha);
+    } else {
+      o = v3(q.ox[i], q.oy[i], q.oz[i]);
+      d = v3(q.dx[i], q.dy[i], q.dz[i]);
+    }
     if (COUNT) c_seg++;
-
-    /* ganesha Floor.intersect (main.ml:247-256): f1 then f2, the first hit clips t_max for the tree */
-    if (MODE == PT_MODE_ARRAY && sc.n_floor > 0) {
-      for (int f = 0; f < sc.n_floor; ++f) {
-        const double* tv = sc.tri + (size_t)(sc.n_slots + f) * 10;
-        double t, u, v;
-        if (COUNT) c_floor++;
-        if (pt_triangle_intersect(pt_load_v3(tv), pt_load_v3(tv + 3), pt_load_v3(tv + 6), o, d, 0.0, PT_MAX_FINITE,
-                                  &t, &u, &v)) {
-          t_best = t;
-          u_best = u;
-          v_best = v;
-          slot_best = sc.n_slots + f;
-          break;
-        }
-      }
-    }
-
-    /* packet constants of spheres_intersect_aux (lib.rs:115-117): a is the UNFUSED scalar dot */
-    double qa = 0.0, one_over_a = 0.0;
-    if (MODE == PT_MODE_SIMD) {
-      qa = d.x * d.x + d.y * d.y + d.z * d.z;
-      one_over_a = 1.0 / qa;
-    }
-
-    if (sc.n_nodes > 0) {
-      int sp = 0;
-      uint32_t node = 0;
-      for (;;) {
-        const PtNode* np = sc.nodes + node;
-        PtNode nd;
-        nd.mn[0] = np->mn[0]; nd.mn[1] = np->mn[1]; nd.mn[2] = np->mn[2];
-        nd.mx[0] = np->mx[0]; nd.mx[1] = np->mx[1]; nd.mx[2] = np->mx[2];
-        nd.a = np->a; nd.b = np->b;
-        if (COUNT) c_nodes++;
-        bool descend = false;
-        if (pt_slab_hit(nd, o, inv, t_min, t_best)) {
-          const uint32_t axis = nd.b >> 30;
-          if (axis == PT_NODE_LEAF_AXIS) {
-            const int first = (int)nd.a;
-            const int len = (int)(nd.b & 0x3fffffffu);
-            if (COUNT) c_prims += (unsigned long long)len;
-            if (MODE == PT_MODE_SIMD) {
-              /* spheres_intersect_aux, lib.rs:102-178, one packet lane per iteration; padded NaN slots
-               * produce NaN and are never selected, exactly like the AVX lanes */
-              for (int k = 0; k < len; ++k) {
-                const double* s = sc.sph + (size_t)(first + k) * 4;
-                const double fx = s[0] - o.x, fy = s[1] - o.y, fz = s[2] - o.z;
-                const double r2 = s[3] * s[3];
-                const double c = pt_fma(fx, fx, pt_fma(fy, fy, fz * fz)) - r2;
-                const double bp = pt_fma(fx, d.x, pt_fma(fy, d.y, fz * d.z));
-                const double bp_over_a = bp * one_over_a;
-                const double wx = pt_fma(d.x, bp_over_a, -fx);
-                const double wy = pt_fma(d.y, bp_over_a, -fy);
-                const double wz = pt_fma(d.z, bp_over_a, -fz);
-                const double wq = pt_fma(wx, wx, pt_fma(wy, wy, wz * wz));
-                const double disc = r2 - wq;
-                /* lanes whose discriminant has its sign bit set (or is NaN) end up NaN: skip them */
-                if (disc == disc && !pt_signbit(disc)) {
-                  const double q_rhs = pt_sqrt(qa * disc);
-                  const double qq = pt_signbit(bp) ? (bp - q_rhs) : (bp + q_rhs);
-                  const double t = pt_signbit(c) ? (qq * one_over_a) : (c / qq);
-                  /* not (t < t_min), not (t > t_max), then `t <= t_found` (last index wins ties) */
-                  if (!(t < t_min) && t <= t_best) {
-                    t_best = t;
-                    slot_best = first + k;
-                  }
-                }
-              }
-            } else {
-              /* Array_leaf.intersect, shape_tree.ml:299-311: shrinking t_max, later element wins ties */
-              for (int k = 0; k < len; ++k) {
-                const int slot = first + k;
-                if (sc.slot_kind[slot] == PT_SLOT_SPHERE) {
-                  const double* s = sc.sph + (size_t)slot * 4;
-                  double t;
-                  if (pt_sphere_intersect_scalar(v3(s[0], s[1], s[2]), s[3], o, d, t_min, t_best, &t)) {
-                    t_best = t;
-                    slot_best = slot;
-                  }
-                } else {
-                  const double* tv = sc.tri + (size_t)slot * 10;
-                  double t, u, v;
-                  if (pt_triangle_intersect(pt_load_v3(tv), pt_load_v3(tv + 3), pt_load_v3(tv + 6), o, d, t_min,
-                                            t_best, &t, &u, &v)) {
-                    t_best = t;
-                    u_best = u;
-                    v_best = v;
-                    slot_best = slot;
-                  }
-                }
-              }
-            }
-          } else {
-            /* Branch: near child first (shape_tree.ml:209), far child deferred */
-            const uint32_t lhs = nd.a, rhs = nd.b & 0x3fffffffu;
-            const bool lhs_first = (dirs >> axis) & 1u;
-            const uint32_t near_c = lhs_first ? lhs : rhs, far_c = lhs_first ? rhs : lhs;
-            stack[sp * PT_WAVE] = far_c;
-            ++sp;
-            node = near_c;
-            descend = true;
-          }
-        }
-        if (!descend) {
-          if (sp == 0) break;
-          --sp;
-          node = stack[sp * PT_WAVE];
-        }
-      }
-    }
-    hits.t[i] = t_best;
-    hits.slot[i] = slot_best;
+    const PtTraceResult r = pt_trace_ray<MODE, COUNT, StackT>(sc, sv, stack, o, d, c_nodes, c_prims, c_floor);
+    hits.t[i] = r.t;
+    hits.slot[i] = r.slot;
     if (MODE == PT_MODE_ARRAY && sc.has_triangles) {
-      hits.u[i] = u_best;
-      hits.v[i] = v_best;
+      hits.u[i] = r.u;
+      hits.v[i] = r.v;
     }
   }
   if (COUNT) {
@@ -445,33 +558,68 @@ struct PtContrib {
   double *r, *g, *b;
 };
 
-/* The body of `loop` in Integrator.path_tracer (integrator.ml:30-66) for one segment of every live path:
- * consumes (ray, hit), writes either the path's final colour or the next ray into `out`. */
-template <bool EMIT>
-__global__ __launch_bounds__(256) void k_shade(PtSceneDev sc, PtQueue q, PtHits hits, PtQueue out, PtContrib contrib,
-                                               const double* __restrict__ alpha, int bounce, int last_bounce) {
-  const uint32_t n = *q.count;
-  const uint32_t waves_per_block = blockDim.x >> 6;
-  const uint32_t gwave = blockIdx.x * waves_per_block + (threadIdx.x >> 6);
-  const uint32_t nwaves = gridDim.x * waves_per_block;
+/* block-aggregated append: ONE atomic per workgroup iteration instead of one per wave (a single
+ * counter word sustains only ~88 atomics/us chip-wide -- MI355X_MICROARCH.md "dequeue" -- which capped a
+ * per-wave scheme at ~5.6 G paths/s).  lds: blockDim/64 + 1 words.  Must be called by every thread. */
+__device__ __forceinline__ uint32_t pt_block_append(uint32_t* counter, bool keep, uint32_t* lds) {
+  const unsigned long long mask = __ballot(keep);
   const int lane = pt_lane();
+  const int wave = (int)(threadIdx.x >> 6), nw = (int)(blockDim.x >> 6);
+  const uint32_t rank = (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+  if (lane == 0) lds[wave] = (uint32_t)__popcll(mask);
+  __syncthreads();
+  uint32_t before = 0, total = 0;
+  for (int w = 0; w < nw; ++w) {
+    const uint32_t c = lds[w];
+    before += (w < wave) ? c : 0u;
+    total += c;
+  }
+  if (threadIdx.x == 0) lds[nw] = total ? atomicAdd(counter, total) : 0u;
+  __syncthreads();
+  const uint32_t base = lds[nw];
+  __syncthreads();
+  return base + before + rank;
+}
+
+/* The body of `loop` in Integrator.path_tracer (integrator.ml:30-66) for one segment of every live path:
+ * consumes (ray, hit), writes either the path's final colour or the next ray into `out`.
+ * PRIMARY: bounce 0 -- the ray, attn0 = white and emit0 = black are recomputed, not read. */
+template <bool EMIT, bool PRIMARY>
+__global__ __launch_bounds__(1024) void k_shade(PtSceneDev sc, PtQueue q, PtHits hits, PtQueue out, PtContrib contrib,
+                                                const double* __restrict__ alpha, int bounce, int last_bounce,
+                                                PtGenParams g, uint32_t n_primary) {
+  __shared__ uint32_t lds_append[17];
+  const uint32_t n = PRIMARY ? n_primary : *q.count;
   const double pi = 3.14159265358979323846;
 
-  for (uint32_t chunk = gwave; (unsigned long long)chunk * PT_WAVE < n; chunk += nwaves) {
-    const uint32_t i = chunk * PT_WAVE + lane;
-    const bool live = i < n;
+  for (uint32_t base_i = blockIdx.x * blockDim.x; base_i < n; base_i += gridDim.x * blockDim.x) {
+    const uint32_t i = base_i + threadIdx.x;
+    bool live = i < n;
     bool keep = false;
     V3 n_o = v3(0, 0, 0), n_d = v3(0, 0, 0), n_attn = v3(0, 0, 0), n_emit = v3(0, 0, 0);
     uint32_t id = 0;
     int offset = 0;
+    PtPrimarySample ps;
+    if (PRIMARY && live) {
+      ps = pt_primary_decode(g, i);
+      live = ps.valid;
+    }
     if (live) {
-      const V3 o = v3(q.ox[i], q.oy[i], q.oz[i]);
-      const V3 d = v3(q.dx[i], q.dy[i], q.dz[i]);
-      const V3 attn0 = v3(q.ar[i], q.ag[i], q.ab[i]);
-      V3 emit0 = v3(0.0, 0.0, 0.0);
-      if (EMIT) emit0 = v3(q.er[i], q.eg[i], q.eb[i]);
-      id = q.id[i];
-      offset = q.offset[i];
+      V3 o, d, attn0, emit0 = v3(0.0, 0.0, 0.0);
+      if (PRIMARY) {
+        o = v3(0.0, 0.0, 0.0);
+        d = pt_primary_dir(sc, g, ps, alpha);
+        attn0 = v3(1.0, 1.0, 1.0); /* Color.white, integrator.ml:68 */
+        id = ps.id;
+        offset = ps.offset;
+      } else {
+        o = v3(q.ox[i], q.oy[i], q.oz[i]);
+        d = v3(q.dx[i], q.dy[i], q.dz[i]);
+        attn0 = v3(q.ar[i], q.ag[i], q.ab[i]);
+        if (EMIT) emit0 = v3(q.er[i], q.eg[i], q.eb[i]);
+        id = q.id[i];
+        offset = q.offset[i];
+      }
       const int slot = hits.slot[i];
       V3 result = v3(0, 0, 0);
       bool done = true;
@@ -608,7 +756,7 @@ __global__ __launch_bounds__(256) void k_shade(PtSceneDev sc, PtQueue q, PtHits 
         keep = true;
       }
     }
-    const uint32_t dst = pt_wave_append(out.count, keep);
+    const uint32_t dst = pt_block_append(out.count, keep, lds_append);
     if (keep) {
       out.ox[dst] = n_o.x; out.oy[dst] = n_o.y; out.oz[dst] = n_o.z;
       out.dx[dst] = n_d.x; out.dy[dst] = n_d.y; out.dz[dst] = n_d.z;

@@ -25,7 +25,7 @@ struct __attribute__((aligned(64))) PtNode {
   double mx[3];
   uint32_t a; /* branch: index of lhs        | leaf: first slot            */
   uint32_t b; /* branch: index of rhs + axis<<30 | leaf: slot count + 3<<30 */
-  uint32_t pad[2];
+  uint32_t pad[2]; /* leaf: pad[0] = number of real (non-padding) slots */
 };
 
 #define PT_SLOT_SPHERE 0
