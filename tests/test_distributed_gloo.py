@@ -1,0 +1,71 @@
+"""Multi-rank path on CPU: world_size 2 and 3 over gloo.  Each rank produces the raw sums of ITS interleaved
+row bands (here taken from the oracle's raw per-pixel sums -- the renderer itself needs a GPU), the ranks
+gather to rank 0 with path_tracer_ocaml_amd.distributed.gather_raw_to_root, and rank 0 must hold exactly
+the single-process raw sums.  Also checks that the Python band layout and the C ABI's ptx_local_rows /
+ptx_global_row agree."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world, port, height, width, raw_path, out_path):
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    import path_tracer_ocaml_amd as P
+    from path_tracer_ocaml_amd import distributed as D
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    full = np.load(raw_path)
+    params = P.render_params(width, height, 1, 1, band_rows=D.BAND_ROWS, band_first=rank, band_step=world)
+    rows = P.local_rows(params)
+    layout = D.band_layout(height, world)
+    assert rows == len(layout[rank])
+    assert [P.global_row(params, k) for k in range(rows)] == layout[rank].tolist()
+    part = torch.from_numpy(full[layout[rank]].copy())  # what ptx_render_raw_device would have produced
+    got = D.gather_raw_to_root(part, height, width, rank, world)
+    if rank == 0:
+        np.save(out_path, got.numpy())
+    else:
+        assert got is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,height", [(2, 150), (3, 100), (2, 31)])
+def test_band_gather_over_gloo(oracle, tmp_path, world, height):
+    import torch.multiprocessing as mp
+    width = 64
+    d = oracle.desc_shirley(width, height)
+    raw = oracle.Scene(d.ptr, d).render(width, height, 2, 4, threads=4, want_raw=True)["raw"]
+    raw_path, out_path = str(tmp_path / "raw.npy"), str(tmp_path / "out.npy")
+    np.save(raw_path, raw)
+    mp.spawn(_worker, args=(world, _free_port(), height, width, raw_path, out_path), nprocs=world, join=True)
+    got = np.load(out_path)
+    assert np.array_equal(got.view(np.uint64), raw.view(np.uint64))
+
+
+def test_band_layout_properties():
+    from path_tracer_ocaml_amd import distributed as D
+    for h in (1, 32, 33, 1080, 2160):
+        for w in (1, 2, 4, 8):
+            rows = D.band_layout(h, w)
+            allrows = np.concatenate(rows)
+            assert sorted(allrows.tolist()) == list(range(h))
+            # interleaving balances the load: no rank owns more than one band beyond its share
+            assert max(len(r) for r in rows) - min(len(r) for r in rows) <= D.BAND_ROWS
