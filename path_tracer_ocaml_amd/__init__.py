@@ -16,7 +16,8 @@ import numpy as np
 from . import abi
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libptx_hip.so")
+# PTX_LIB overrides the library path (kernel-variant experiments); the default is the in-tree build
+LIB_PATH = os.environ.get("PTX_LIB") or os.path.join(_HERE, "libptx_hip.so")
 _LIB = None
 
 dp = abi.c_double_p

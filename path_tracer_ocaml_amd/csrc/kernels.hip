@@ -246,6 +246,10 @@ struct PtTraceResult {
 #define PT_STACK_PUSH(stk, sp, val) ((stk)[(sp) * PT_WAVE] = (StackT)(val))
 #define PT_STACK_POP(stk, sp) ((uint32_t)(stk)[(sp) * PT_WAVE])
 
+#ifndef PT_WALK_MIN
+#define PT_WALK_MIN 8
+#endif
+
 template <int MODE, bool COUNT, typename StackT>
 __device__ __forceinline__ PtTraceResult pt_trace_ray(const PtSceneDev& sc, const PtSceneView& sv, StackT* stack,
                                                       V3 o, V3 d, unsigned long long& c_nodes,
@@ -295,7 +299,14 @@ __device__ __forceinline__ PtTraceResult pt_trace_ray(const PtSceneDev& sc, cons
   bool walking = true;
   int leaf_first = 0, leaf_n = 0;
   while (walking || leaf_n > 0) {
-    while (walking && leaf_n == 0) {
+    for (;;) {
+      /* keep walking while enough lanes still want a node step; once fewer than PT_WALK_MIN do and some lane
+       * already holds a leaf, intersect the pending packets first (the stragglers resume afterwards) */
+      const bool want = walking && leaf_n == 0;
+      const unsigned long long wm = __ballot(want);
+      if (wm == 0) break;
+      if ((int)__popcll(wm) < PT_WALK_MIN && __ballot(leaf_n > 0) != 0) break;
+      if (!want) continue;
       const PtNode* np = sv.nodes + node;
       if (COUNT) c_nodes++;
       bool descend = false;
@@ -329,28 +340,39 @@ __device__ __forceinline__ PtTraceResult pt_trace_ray(const PtSceneDev& sc, cons
     }
     if (leaf_n > 0) {
       if (MODE == PT_MODE_SIMD) {
-        /* spheres_intersect_aux, lib.rs:102-178, one packet lane per iteration */
-        for (int k = 0; k < leaf_n; ++k) {
-          const double* s = sv.sph + (size_t)(leaf_first + k) * 4;
-          const double fx = s[0] - o.x, fy = s[1] - o.y, fz = s[2] - o.z;
-          const double r2 = s[3] * s[3];
-          const double c = pt_fma(fx, fx, pt_fma(fy, fy, fz * fz)) - r2;
-          const double bp = pt_fma(fx, d.x, pt_fma(fy, d.y, fz * d.z));
-          const double bp_over_a = bp * one_over_a;
-          const double wx = pt_fma(d.x, bp_over_a, -fx);
-          const double wy = pt_fma(d.y, bp_over_a, -fy);
-          const double wz = pt_fma(d.z, bp_over_a, -fz);
-          const double wq = pt_fma(wx, wx, pt_fma(wy, wy, wz * wz));
-          const double disc = r2 - wq;
-          /* lanes whose discriminant has its sign bit set (or is NaN) end up NaN: skip them */
-          if (disc == disc && !pt_signbit(disc)) {
+        /* spheres_intersect_aux, lib.rs:102-178, one packet lane per step, split in two so the wave stays
+         * dense: SCAN (cheap, every lane: f, c, b', discriminant) runs until the lane meets a slot whose
+         * discriminant is >= +0; only then do the lanes that found one run the HEAVY part (sqrt, divide)
+         * together.  Testing slot after slot in lockstep would execute ~50 sqrt/div instructions per slot with
+         * one lane in eight active.  Slots are still visited in order, so `t <= t_found` ties resolve alike. */
+        int k = 0;
+        while (k < leaf_n) {
+          double c = 0.0, bp = 0.0, disc = 0.0;
+          bool found = false;
+          while (k < leaf_n && !found) {
+            const double* s = sv.sph + (size_t)(leaf_first + k) * 4;
+            const double fx = s[0] - o.x, fy = s[1] - o.y, fz = s[2] - o.z;
+            const double r2 = s[3] * s[3];
+            c = pt_fma(fx, fx, pt_fma(fy, fy, fz * fz)) - r2;
+            bp = pt_fma(fx, d.x, pt_fma(fy, d.y, fz * d.z));
+            const double bp_over_a = bp * one_over_a;
+            const double wx = pt_fma(d.x, bp_over_a, -fx);
+            const double wy = pt_fma(d.y, bp_over_a, -fy);
+            const double wz = pt_fma(d.z, bp_over_a, -fz);
+            const double wq = pt_fma(wx, wx, pt_fma(wy, wy, wz * wz));
+            disc = r2 - wq;
+            /* lanes whose discriminant has its sign bit set (or is NaN) end up NaN (lib.rs:162-166) */
+            found = (disc == disc) && !pt_signbit(disc);
+            ++k;
+          }
+          if (found) {
             const double q_rhs = pt_sqrt(qa * disc);
             const double qq = pt_signbit(bp) ? (bp - q_rhs) : (bp + q_rhs);
             const double t = pt_signbit(c) ? (qq * one_over_a) : (c / qq);
-            /* not (t < t_min), not (t > t_max), then `t <= t_found` (last index wins ties) */
+            /* not (t < t_min), not (t > t_max), then `t <= t_found` (last index wins ties, lib.rs:169-177) */
             if (!(t < t_min) && t <= r.t) {
               r.t = t;
-              r.slot = leaf_first + k;
+              r.slot = leaf_first + k - 1;
             }
           }
         }
@@ -584,16 +606,62 @@ __device__ __forceinline__ uint32_t pt_block_append(uint32_t* counter, bool keep
 /* The body of `loop` in Integrator.path_tracer (integrator.ml:30-66) for one segment of every live path:
  * consumes (ray, hit), writes either the path's final colour or the next ray into `out`.
  * PRIMARY: bounce 0 -- the ray, attn0 = white and emit0 = black are recomputed, not read. */
+#ifndef PT_SHADE_SORT
+#define PT_SHADE_SORT 1
+#endif
+
+/* Workgroup-local counting sort of the next blockDim entries by shading category (miss / Lambertian solid /
+ * Lambertian checker / metal / dielectric): after it, thread t handles entry perm[t] and every wave executes
+ * (almost) one category.  Unsorted, a secondary wave holds all of them at once and runs the sum of their code
+ * paths with ~40 % of its lanes active.  lds_cnt: PT_N_CAT * (blockDim/64) words; perm: blockDim u16. */
+__device__ __forceinline__ uint32_t pt_block_sort_by_category(int key, uint32_t* lds_cnt, uint16_t* perm) {
+  const int lane = pt_lane();
+  const int wave = (int)(threadIdx.x >> 6), nw = (int)(blockDim.x >> 6);
+  uint32_t rank = 0;
+#pragma unroll
+  for (int k = 0; k < PT_N_CAT; ++k) {
+    const unsigned long long m = __ballot(key == k);
+    if (key == k) rank = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+    if (lane == 0) lds_cnt[k * nw + wave] = (uint32_t)__popcll(m);
+  }
+  __syncthreads();
+  if (wave == 0) { /* exclusive prefix over the (category-major, wave-minor) table: <= 64 entries */
+    const int entries = PT_N_CAT * nw;
+    uint32_t v = lane < entries ? lds_cnt[lane] : 0u;
+    uint32_t incl = v;
+    for (int off = 1; off < 64; off <<= 1) {
+      const uint32_t up = (uint32_t)__shfl_up((int)incl, off, 64);
+      if (lane >= off) incl += up;
+    }
+    if (lane < entries) lds_cnt[lane] = incl - v;
+  }
+  __syncthreads();
+  const uint32_t pos = lds_cnt[key * nw + wave] + rank;
+  perm[pos] = (uint16_t)threadIdx.x;
+  __syncthreads();
+  return (uint32_t)perm[threadIdx.x];
+}
+
 template <bool EMIT, bool PRIMARY>
-__global__ __launch_bounds__(1024) void k_shade(PtSceneDev sc, PtQueue q, PtHits hits, PtQueue out, PtContrib contrib,
+__global__ __launch_bounds__(512, 4) void k_shade(PtSceneDev sc, PtQueue q, PtHits hits, PtQueue out, PtContrib contrib,
                                                 const double* __restrict__ alpha, int bounce, int last_bounce,
                                                 PtGenParams g, uint32_t n_primary) {
   __shared__ uint32_t lds_append[17];
+  __shared__ uint32_t lds_cnt[PT_N_CAT * 8];
+  __shared__ uint16_t lds_perm[512];
   const uint32_t n = PRIMARY ? n_primary : *q.count;
   const double pi = 3.14159265358979323846;
 
   for (uint32_t base_i = blockIdx.x * blockDim.x; base_i < n; base_i += gridDim.x * blockDim.x) {
-    const uint32_t i = base_i + threadIdx.x;
+    uint32_t i = base_i + threadIdx.x;
+    if (PT_SHADE_SORT && !PRIMARY) {
+      int key = PT_CAT_NONE;
+      if (i < n) {
+        const int sl = hits.slot[i];
+        key = sl < 0 ? PT_CAT_MISS : (int)sc.slot_cat[sl];
+      }
+      i = base_i + pt_block_sort_by_category(key, lds_cnt, lds_perm);
+    }
     bool live = i < n;
     bool keep = false;
     V3 n_o = v3(0, 0, 0), n_d = v3(0, 0, 0), n_attn = v3(0, 0, 0), n_emit = v3(0, 0, 0);

@@ -32,6 +32,15 @@ struct __attribute__((aligned(64))) PtNode {
 #define PT_SLOT_TRIANGLE 1
 #define PT_SLOT_PAD 2 /* NaN padding slot of a Simd_leaf packet */
 
+/* shading categories: what a segment will execute in the shade stage */
+#define PT_CAT_MISS 0
+#define PT_CAT_LAMBERT_SOLID 1
+#define PT_CAT_LAMBERT_CHECKER 2
+#define PT_CAT_METAL 3
+#define PT_CAT_DIELECTRIC 4
+#define PT_CAT_NONE 5 /* beyond the end of the queue */
+#define PT_N_CAT 6
+
 /* scene "mode" = which Leaf implementation the tree was built with */
 #define PT_MODE_SIMD 0  /* Simd_leaf packets: every slot a sphere, Rust x86 arithmetic */
 #define PT_MODE_ARRAY 1 /* Array_leaf: spheres (scalar Sphere.intersect) and/or triangles */
@@ -63,6 +72,7 @@ struct PtSceneDev {
   const double* tri;   /* n_slots x 10 (valid where slot_kind == TRIANGLE); NULL if no triangles */
   const double* tri_uv;/* n_slots x 6 */
   const uint8_t* slot_kind;
+  const uint8_t* slot_cat;  /* shading category of the slot's material, PT_CAT_* (wave-coherent shading) */
   const int32_t* slot_material;
   const int32_t* slot_prim; /* build-list primitive index, -1 for padding */
   /* floor triangles tested before the tree (ganesha Floor): appended after the tree slots
