@@ -91,6 +91,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--passes-per-batch", type=int, default=0)
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="gloo = rehearsal of the multi-rank path on fewer GPUs than ranks (ranks share devices)")
     args = ap.parse_args()
 
     import torch
@@ -106,15 +108,22 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     if not torch.cuda.is_available():
         raise SystemExit("no GPU visible: this benchmark has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    n_dev = torch.cuda.device_count()
+    if args.backend == "nccl" and local_rank >= n_dev:
+        raise SystemExit(f"rank {rank}: local rank {local_rank} but only {n_dev} GPU(s) visible")
+    local_dev = local_rank % n_dev  # gloo rehearsal: ranks may share a device
+    torch.cuda.set_device(local_dev)
+    dev = torch.device("cuda", local_dev)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group("gloo")
 
     scene_name, w, h, spp, depth = WORKLOADS[args.workload]
     hs = build_scene(H, scene_name, w, h)
-    scene = P.Scene(hs.ptr, local_rank, keepalive=hs)
+    scene = P.Scene(hs.ptr, local_dev, keepalive=hs)
     sstats = scene.stats()
 
     params = P.render_params(w, h, spp, depth, band_rows=D.BAND_ROWS, band_first=rank, band_step=world,
@@ -128,7 +137,7 @@ def main():
         st = scene.render_raw_device(params, part.data_ptr(), stream)
         full = D.gather_raw_to_root(part, h, w, rank, world, D.BAND_ROWS)
         if rank == 0:
-            P.film_resolve_device(local_rank, w, h, spp, full.data_ptr(), rgb.data_ptr(), stream)
+            P.film_resolve_device(local_dev, w, h, spp, full.data_ptr(), rgb.data_ptr(), stream)
         return st
 
     def fence():
@@ -150,7 +159,8 @@ def main():
             launches[k] += st["kernel_launches"][k]
     fence()
     elapsed = time.perf_counter() - t0
-    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    cdev = dev if args.backend == "nccl" else torch.device("cpu")  # where the tiny control tensors live
+    t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
@@ -160,7 +170,7 @@ def main():
                               passes_per_batch=args.passes_per_batch)
     cst = scene.render_raw_device(cparams, part.data_ptr(), stream)
     keys = ("samples", "segments", "nodes_tested", "prims_tested", "floor_tested")
-    cvec = torch.tensor([float(cst[k]) for k in keys] + [kernel_ms["trace"], launches["trace"]], dtype=torch.float64, device=dev)
+    cvec = torch.tensor([float(cst[k]) for k in keys] + [kernel_ms["trace"], launches["trace"]], dtype=torch.float64, device=cdev)
     if world > 1:
         # counters: sum over ranks; trace time: the slowest rank bounds the job, launches: per rank
         summed = cvec.clone()
@@ -196,12 +206,17 @@ def main():
                        "sharding": f"{world} rank(s), interleaved {D.BAND_ROWS}-row bands, 1 gather/step" if world > 1 else "1 rank",
                        "tree_nodes": sstats["tree_nodes"], "tree_depth": sstats["tree_depth"], "leaf_slots": sstats["leaf_slots"]},
             "roofline": {
-                "bound": "hbm", "kernel": "k_trace", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                # N ranks: whole-job bytes over the slowest rank's kernel time, against N GPUs' HBM
+                "bound": "hbm", "kernel": "k_trace", "achieved": achieved, "peak": HBM_PEAK_GBS * world, "unit": "GB/s",
+                "frac": achieved / (HBM_PEAK_GBS * world), "traffic": traffic,
                 "algorithmic_bytes_per_launch": b_trace / max(trace_launches / args.steps, 1.0),
                 "launches_per_step": trace_launches / args.steps, "avg_launch_ms": trace_ms_total / max(trace_launches, 1.0),
                 "pipeline": {"bytes_per_sample": b_total / samples, "achieved": b_total * args.steps / elapsed * 1e-9,
-                             "frac": b_total * args.steps / elapsed * 1e-9 / HBM_PEAK_GBS},
+                             "frac": b_total * args.steps / elapsed * 1e-9 / (HBM_PEAK_GBS * world)},
+                # the kernel's real ceiling: f64 vector issue.  27 flop per node test (6 sub, 6 mul, 12 min/max,
+                # 2 clamps, 1 compare), 24 per packet slot (scan part), against 78.6 TFLOP/s f64 vector peak
+                "valu_f64": {"achieved_tflops": (counts["nodes_tested"] * 27.0 + counts["prims_tested"] * 24.0) / (trace_ms_step * 1e-3) * 1e-12 if trace_ms_step > 0 else 0.0,
+                             "peak_tflops": 78.6 * world},
             },
             "kernel_ms_per_step": {k: v / args.steps for k, v in kernel_ms.items()},
             "work": {**counts, "segments_per_sample": counts["segments"] / samples,

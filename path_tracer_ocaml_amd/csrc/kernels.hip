@@ -603,6 +603,45 @@ __device__ __forceinline__ uint32_t pt_block_append(uint32_t* counter, bool keep
   return base + before + rank;
 }
 
+
+#ifndef PT_APPEND_BINS
+#define PT_APPEND_BINS 8
+#endif
+/* block-aggregated append that also BINS the survivors of this workgroup iteration by `key` (the direction
+ * octant of the new ray): inside the workgroup's slice of the output queue, rays of one octant are contiguous,
+ * so the waves of the next trace launch walk the tree in the same child order.  One atomic per iteration.
+ * lds: PT_APPEND_BINS * (blockDim/64) + 1 words (<= 65). */
+__device__ __forceinline__ uint32_t pt_block_append_binned(uint32_t* counter, bool keep, int key, uint32_t* lds) {
+  const int lane = pt_lane();
+  const int wave = (int)(threadIdx.x >> 6), nw = (int)(blockDim.x >> 6);
+  uint32_t rank = 0;
+#pragma unroll
+  for (int k = 0; k < PT_APPEND_BINS; ++k) {
+    const unsigned long long m = __ballot(keep && key == k);
+    if (key == k) rank = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+    if (lane == 0) lds[k * nw + wave] = (uint32_t)__popcll(m);
+  }
+  __syncthreads();
+  if (wave == 0) {
+    const int entries = PT_APPEND_BINS * nw; /* <= 64 */
+    const uint32_t v = lane < entries ? lds[lane] : 0u;
+    uint32_t incl = v;
+    for (int off = 1; off < 64; off <<= 1) {
+      const uint32_t up = (uint32_t)__shfl_up((int)incl, off, 64);
+      if (lane >= off) incl += up;
+    }
+    const uint32_t total = (uint32_t)__shfl((int)incl, 63, 64);
+    uint32_t base = 0;
+    if (lane == 0 && total) base = atomicAdd(counter, total);
+    base = (uint32_t)__shfl((int)base, 0, 64);
+    if (lane < entries) lds[lane] = base + incl - v;
+  }
+  __syncthreads();
+  const uint32_t dst = lds[key * nw + wave] + rank;
+  __syncthreads();
+  return dst;
+}
+
 /* The body of `loop` in Integrator.path_tracer (integrator.ml:30-66) for one segment of every live path:
  * consumes (ray, hit), writes either the path's final colour or the next ray into `out`.
  * PRIMARY: bounce 0 -- the ray, attn0 = white and emit0 = black are recomputed, not read. */
@@ -647,6 +686,7 @@ __global__ __launch_bounds__(512, 4) void k_shade(PtSceneDev sc, PtQueue q, PtHi
                                                 const double* __restrict__ alpha, int bounce, int last_bounce,
                                                 PtGenParams g, uint32_t n_primary) {
   __shared__ uint32_t lds_append[17];
+  __shared__ uint32_t lds_bins[65];
   __shared__ uint32_t lds_cnt[PT_N_CAT * 8];
   __shared__ uint16_t lds_perm[512];
   const uint32_t n = PRIMARY ? n_primary : *q.count;
@@ -824,7 +864,12 @@ __global__ __launch_bounds__(512, 4) void k_shade(PtSceneDev sc, PtQueue q, PtHi
         keep = true;
       }
     }
+#if PT_APPEND_BINS > 1
+    const int octant = (n_d.x >= 0.0 ? 1 : 0) | (n_d.y >= 0.0 ? 2 : 0) | (n_d.z >= 0.0 ? 4 : 0);
+    const uint32_t dst = pt_block_append_binned(out.count, keep, octant, lds_bins);
+#else
     const uint32_t dst = pt_block_append(out.count, keep, lds_append);
+#endif
     if (keep) {
       out.ox[dst] = n_o.x; out.oy[dst] = n_o.y; out.oz[dst] = n_o.z;
       out.dx[dst] = n_d.x; out.dy[dst] = n_d.y; out.dz[dst] = n_d.z;

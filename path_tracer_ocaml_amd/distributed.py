@@ -48,12 +48,16 @@ def gather_raw_to_root(part, height, width, rank, world, band_rows=BAND_ROWS, gr
         send = torch.zeros((pad, width, 3), dtype=part.dtype, device=part.device)
         send[: part.shape[0]] = part
     send = send.contiguous()
-    bufs = [torch.empty_like(send) for _ in range(world)] if rank == 0 else None
-    dist.gather(send, gather_list=bufs, dst=0, group=group)
+    # gloo has no device-tensor gather: stage through the host (rehearsals / CPU tests only; the production
+    # backend is "nccl" = RCCL, device to device over xGMI)
+    staged = dist.get_backend(group) == "gloo" and send.is_cuda
+    wire = send.cpu() if staged else send
+    bufs = [torch.empty_like(wire) for _ in range(world)] if rank == 0 else None
+    dist.gather(wire, gather_list=bufs, dst=0, group=group)
     if rank != 0:
         return None
     full = torch.empty((height, width, 3), dtype=part.dtype, device=part.device)
     for r in range(world):
         idx = torch.as_tensor(layout[r], device=part.device)
-        full[idx] = bufs[r][: len(layout[r])]
+        full[idx] = bufs[r][: len(layout[r])].to(part.device)
     return full
