@@ -12,7 +12,8 @@ HOST_LIB_PATH = os.path.join(_HERE, "libpt_host.so")
 _LIB = None
 
 EXPORTS = ("pth_scene_desc", "pth_scene_free", "pth_camera_create", "pth_scene_shirley", "pth_scene_cornell",
-           "pth_scene_ganesha_like", "pth_write_png")
+           "pth_scene_ganesha_like", "pth_write_png", "pth_last_error", "pth_ply_load", "pth_ply_free", "pth_ply_count",
+           "pth_ply_floats", "pth_ply_ints", "pth_ply_rows", "pth_scene_ganesha_ply", "pth_write_ganesha_like_ply")
 
 
 def lib():
@@ -33,6 +34,21 @@ def lib():
         L.pth_scene_ganesha_like.restype = C.c_void_p
         L.pth_scene_ganesha_like.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_uint64]
         L.pth_write_png.argtypes = [C.c_char_p, C.c_int32, C.c_int32, abi.c_double_p]
+        L.pth_last_error.restype = C.c_char_p
+        L.pth_ply_load.restype = C.c_void_p
+        L.pth_ply_load.argtypes = [C.c_char_p]
+        L.pth_ply_free.argtypes = [C.c_void_p]
+        L.pth_ply_count.restype = C.c_int64
+        L.pth_ply_count.argtypes = [C.c_void_p, C.c_char_p]
+        L.pth_ply_floats.restype = abi.c_double_p
+        L.pth_ply_floats.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p]
+        L.pth_ply_ints.restype = C.POINTER(C.c_int64)
+        L.pth_ply_ints.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p]
+        L.pth_ply_rows.restype = abi.c_int32_p
+        L.pth_ply_rows.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(abi.c_int32_p)]
+        L.pth_scene_ganesha_ply.restype = C.c_void_p
+        L.pth_scene_ganesha_ply.argtypes = [C.c_char_p, C.c_int32, C.c_int32]
+        L.pth_write_ganesha_like_ply.argtypes = [C.c_char_p, C.c_int32, C.c_uint64]
         _LIB = L
     return _LIB
 
@@ -119,3 +135,65 @@ def write_png(path, rgb):
     rc = lib().pth_write_png(path.encode(), w, h, rgb.ctypes.data_as(abi.c_double_p))
     if rc != 0:
         raise IOError(f"pth_write_png({path}) failed: {rc}")
+
+
+class PlyError(RuntimeError):
+    pass
+
+
+class Ply:
+    """Ply.of_bigstring (ply_format/src/ply.ml:340-352) through libpt_host.so."""
+
+    def __init__(self, path):
+        self._h = lib().pth_ply_load(path.encode())
+        if not self._h:
+            raise PlyError(lib().pth_last_error().decode())
+
+    def count(self, key):
+        return int(lib().pth_ply_count(self._h, key.encode()))
+
+    def floats(self, element, prop):
+        p = lib().pth_ply_floats(self._h, element.encode(), prop.encode())
+        return None if not p else np.ctypeslib.as_array(p, shape=(self.count(element),)).copy()
+
+    def ints(self, element, prop):
+        p = lib().pth_ply_ints(self._h, element.encode(), prop.encode())
+        return None if not p else np.ctypeslib.as_array(p, shape=(self.count(element),)).copy()
+
+    def rows(self, list_property):
+        lengths = abi.c_int32_p()
+        p = lib().pth_ply_rows(self._h, list_property.encode(), C.byref(lengths))
+        if not p:
+            return None
+        n = self.count(list_property)
+        ln = np.ctypeslib.as_array(lengths, shape=(n,)).copy() if n else np.zeros(0, dtype=np.int32)
+        flat = np.ctypeslib.as_array(p, shape=(int(ln.sum()),)).copy() if ln.sum() else np.zeros(0, dtype=np.int32)
+        out, k = [], 0
+        for m in ln:
+            out.append(flat[k:k + m])
+            k += m
+        return out
+
+    def close(self):
+        if self._h:
+            lib().pth_ply_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def ganesha_ply(path, width, height):
+    """ganesha/bin/main.ml with -ganesha-ply PATH."""
+    h = lib().pth_scene_ganesha_ply(path.encode(), width, height)
+    if not h:
+        raise PlyError(lib().pth_last_error().decode())
+    return HostScene(h)
+
+
+def write_ganesha_like_ply(path, n_target=150000, seed=7):
+    if lib().pth_write_ganesha_like_ply(path.encode(), n_target, seed) != 0:
+        raise IOError(path)

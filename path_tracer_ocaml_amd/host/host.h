@@ -27,6 +27,22 @@ pth_scene* pth_scene_cornell(int32_t width, int32_t height, double ceiling_emit)
 /* ganesha/bin/main.ml camera / floor / material over a synthetic mesh of ~n_target triangles */
 pth_scene* pth_scene_ganesha_like(int32_t width, int32_t height, int32_t n_target, uint64_t seed);
 
+/* ---- PLY (ply_format/src/ply.ml) ---- */
+typedef struct pth_ply pth_ply;
+const char* pth_last_error(void);
+/* Ply.of_bigstring over the file's bytes: NULL + pth_last_error() on failure */
+pth_ply* pth_ply_load(const char* path);
+void pth_ply_free(pth_ply* p);
+/* number of rows of an element (fixed-width) or of a list PROPERTY (keyed by property name, ply.ml:234); -1 if absent */
+int64_t pth_ply_count(const pth_ply* p, const char* key);
+const double* pth_ply_floats(const pth_ply* p, const char* element, const char* property);  /* Column.Floats */
+const int64_t* pth_ply_ints(const pth_ply* p, const char* element, const char* property);   /* Column.Ints */
+const int32_t* pth_ply_rows(pth_ply* p, const char* list_property, const int32_t** lengths_out); /* Column.Rows, flattened */
+/* ganesha/bin/main.ml with -ganesha-ply PATH: Mesh.create + floor + camera; sky background (extension) */
+pth_scene* pth_scene_ganesha_ply(const char* path, int32_t width, int32_t height);
+/* the synthetic stand-in mesh written as a PLY file with the real model's layout */
+int32_t pth_write_ganesha_like_ply(const char* path, int32_t n_target, uint64_t seed);
+
 /* Bimage_unix.Stb.write of the f64 image (render_command.ml:66-70): 8-bit RGB PNG, v -> int(v*255) clamped.
  * returns 0 on success */
 int32_t pth_write_png(const char* path, int32_t width, int32_t height, const double* rgb);

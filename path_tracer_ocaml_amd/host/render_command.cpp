@@ -29,13 +29,15 @@ struct Args {
   int device = 0;
   int ganesha_triangles = 150000;
   double ceiling_emit = 12.0;
+  std::string ganesha_ply; // -ganesha-ply <file> (ganesha/bin/main.ml:19-24); empty = synthetic stand-in mesh
 };
 
 [[noreturn]] void usage(const char* prog, const char* msg) {
   if (msg) std::fprintf(stderr, "%s: %s\n", prog, msg);
   std::fprintf(stderr,
                "Usage: %s -d WIDTH,HEIGHT [--samples-per-pixel=INT] [-o PATH] [--no-progress]\n"
-               "          [--max-ray-bounces=INT] [--no-simd] [--scene=shirley|cornell|ganesha] [--device=INT]\n",
+               "          [--max-ray-bounces=INT] [--no-simd] [--scene=shirley|cornell|ganesha] [--device=INT]\n"
+               "          [--ganesha-ply=PATH] [--triangles=INT] [--ceiling-emit=FLOAT]\n",
                prog);
   std::exit(msg ? 124 : 0); // Cmdliner exits 124 on a CLI error
 }
@@ -74,6 +76,8 @@ Args parse(int argc, char** argv) {
     else if (take_value(argc, argv, i, "device", nullptr, &v)) a.device = std::atoi(v.c_str());
     else if (take_value(argc, argv, i, "triangles", nullptr, &v)) a.ganesha_triangles = std::atoi(v.c_str());
     else if (take_value(argc, argv, i, "ceiling-emit", nullptr, &v)) a.ceiling_emit = std::atof(v.c_str());
+    else if (take_value(argc, argv, i, "ganesha-ply", nullptr, &v)) a.ganesha_ply = v;
+    else if (!std::strcmp(argv[i], "-ganesha-ply") && i + 1 < argc) a.ganesha_ply = argv[++i]; // Stdlib.Arg spelling
     else if (!std::strcmp(argv[i], "--no-progress")) a.no_progress = true;
     else if (!std::strcmp(argv[i], "--no-simd")) a.no_simd = true;
     else if (!std::strcmp(argv[i], "--help") || !std::strcmp(argv[i], "-h")) usage(argv[0], nullptr);
@@ -112,7 +116,13 @@ int main(int argc, char** argv) {
   pth_scene* hs = nullptr;
   if (a.scene == "shirley") hs = pth_scene_shirley(a.width, a.height, a.no_simd ? 1 : 0, 42); // Random.init 42
   else if (a.scene == "cornell") hs = pth_scene_cornell(a.width, a.height, a.ceiling_emit);
-  else if (a.scene == "ganesha") hs = pth_scene_ganesha_like(a.width, a.height, a.ganesha_triangles, 7);
+  else if (a.scene == "ganesha") {
+    hs = a.ganesha_ply.empty() ? pth_scene_ganesha_like(a.width, a.height, a.ganesha_triangles, 7) : pth_scene_ganesha_ply(a.ganesha_ply.c_str(), a.width, a.height);
+    if (!hs) {
+      std::fprintf(stderr, "%s\n", pth_last_error());
+      return 1;
+    }
+  }
   else usage(argv[0], "unknown --scene");
   const ptx_scene_desc* d = pth_scene_desc(hs);
   std::printf("dim = %d x %d;\n", a.width, a.height);

@@ -372,13 +372,11 @@ pth_scene* pth_scene_cornell(int32_t width, int32_t height, double ceiling_emit)
   return s;
 }
 
-// Synthetic "ganesha-like" scene (the real ganesha.ply is not in the reference repository): a closed
-// lat-long surface of about n_target triangles displaced by seeded lobes, the reference's camera,
-// Lambertian (.1,.7,.2), the 500x500 checker floor tested before the tree, sky background (extension).
-pth_scene* pth_scene_ganesha_like(int32_t width, int32_t height, int32_t n_target, uint64_t seed) {
-  pth_scene* s = new pth_scene();
-  const Camera cam = camera_create(v3(328.0, 70.282, 345.0), v3(328.0, 10.0, 0.0), v3(-0.00212272, 0.998201, -0.0599264), (double)width / (double)height, 30.0);
-  const int mat = s->material(PTX_MAT_LAMBERTIAN, s->solid(0.1, 0.7, 0.2));
+// Synthetic "ganesha-like" mesh (the real ganesha.ply is not in the reference repository): a closed
+// lat-long surface of about n_target triangles displaced by seeded lobes; world-space vertices rounded to
+// float32 like a PLY `float` property.
+static void ganesha_like_mesh(int32_t n_target, uint64_t seed, std::vector<double>& X, std::vector<double>& Y,
+                              std::vector<double>& Z, std::vector<int32_t>& tri) {
   int nv = (int)std::floor(std::sqrt((double)n_target / 4.0));
   if (nv < 4) nv = 4;
   const int nu = 2 * nv;
@@ -408,21 +406,38 @@ pth_scene* pth_scene_ganesha_like(int32_t width, int32_t height, int32_t n_targe
       double disp = 1.0;
       for (const Lobe& l : lobes) disp += l.amp * std::exp(l.sharp * ((n.x * l.x + n.y * l.y + n.z * l.z) - 1.0));
       disp += 0.02 * std::sin(37.0 * ph) * std::sin(29.0 * th);
-      V3 p = v3(centre.x + radii.x * disp * n.x, centre.y + radii.y * disp * n.y, centre.z + radii.z * disp * n.z);
-      p = v3((double)(float)p.x, (double)(float)p.y, (double)(float)p.z); // a PLY `float` property
-      vid[(size_t)j * nu + i] = s->vertex(camera_transform(cam, p));   // Mesh.create (main.ml:74-79)
+      const V3 p = v3(centre.x + radii.x * disp * n.x, centre.y + radii.y * disp * n.y, centre.z + radii.z * disp * n.z);
+      vid[(size_t)j * nu + i] = (int)X.size();
+      X.push_back((double)(float)p.x); // a PLY `float` property
+      Y.push_back((double)(float)p.y);
+      Z.push_back((double)(float)p.z);
     }
   }
-  double uv[6];
-  uv3(uv, kT00, kT01, kT11); // tex_coords = (t00, t01, t11), main.ml:111
   for (int j = 0; j < nv; ++j)
     for (int i = 0; i < nu; ++i) {
       const int i1 = (i + 1) % nu;
       const int a = vid[(size_t)j * nu + i], b = vid[(size_t)j * nu + i1], c = vid[(size_t)(j + 1) * nu + i1], d = vid[(size_t)(j + 1) * nu + i];
-      if (j != 0) s->triangle(a, b, c, uv, mat);
-      if (j != nv - 1) s->triangle(a, c, d, uv, mat);
+      if (j != 0) { tri.push_back(a); tri.push_back(b); tri.push_back(c); }
+      if (j != nv - 1) { tri.push_back(a); tri.push_back(c); tri.push_back(d); }
     }
-  { // Floor (main.ml:205-245) under the mesh's camera-space bbox
+}
+
+} // extern "C"
+
+// ganesha/bin/main.ml over a world-space mesh: camera (:30-35), Mesh.create (vertices to camera space, :74-79),
+// Lambertian (.1,.7,.2) with tex_coords (t00,t01,t11) (:111-115), leaf cutoff 8 (:158), the 500x500 checker floor
+// tested before the tree (:205-260).  sky: Shirley's sky background (documented extension -- the reference
+// lights this scene with photon-map spot lights the path integrator ignores).
+pth_scene* pth_scene_ganesha_from_mesh(int32_t width, int32_t height, const std::vector<double>& X, const std::vector<double>& Y,
+                                       const std::vector<double>& Z, const std::vector<int32_t>& tri, bool sky_bg) {
+  pth_scene* s = new pth_scene();
+  const Camera cam = camera_create(v3(328.0, 70.282, 345.0), v3(328.0, 10.0, 0.0), v3(-0.00212272, 0.998201, -0.0599264), (double)width / (double)height, 30.0);
+  const int mat = s->material(PTX_MAT_LAMBERTIAN, s->solid(0.1, 0.7, 0.2));
+  for (size_t i = 0; i < X.size(); ++i) s->vertex(camera_transform(cam, v3(X[i], Y[i], Z[i])));
+  double uv[6];
+  uv3(uv, kT00, kT01, kT11);
+  for (size_t t = 0; t + 2 < tri.size(); t += 3) s->triangle(tri[t], tri[t + 1], tri[t + 2], uv, mat);
+  { // Floor (main.ml:205-245) under the tree's bbox = union of the triangle bboxes
     Box bb{};
     for (size_t t = 0; t < s->tm.size(); ++t) {
       Box tb{};
@@ -457,12 +472,47 @@ pth_scene* pth_scene_ganesha_like(int32_t width, int32_t height, int32_t n_targe
     s->floor_m = {fm, fm};
   }
   s->d.camera = cam.view;
-  sky(s->d.background);
+  if (sky_bg) sky(s->d.background);
+  else {
+    s->d.background = ptx_background{};
+    s->d.background.kind = PTX_BG_BLACK;
+  }
   s->d.leaf_kind = PTX_LEAF_ARRAY;
   s->d.length_cutoff = 8; // ganesha/bin/main.ml:158
   s->d.num_bins = 32;
   s->sync();
   return s;
+}
+
+extern "C" {
+
+pth_scene* pth_scene_ganesha_like(int32_t width, int32_t height, int32_t n_target, uint64_t seed) {
+  std::vector<double> X, Y, Z;
+  std::vector<int32_t> tri;
+  ganesha_like_mesh(n_target, seed, X, Y, Z, tri);
+  return pth_scene_ganesha_from_mesh(width, height, X, Y, Z, tri, true);
+}
+
+// writes the synthetic mesh as a binary little-endian PLY with the real model's layout
+// (element vertex: float x y z; element face: list uint8 int vertex_indices)
+int32_t pth_write_ganesha_like_ply(const char* path, int32_t n_target, uint64_t seed) {
+  std::vector<double> X, Y, Z;
+  std::vector<int32_t> tri;
+  ganesha_like_mesh(n_target, seed, X, Y, Z, tri);
+  FILE* f = std::fopen(path, "wb");
+  if (!f) return -1;
+  std::fprintf(f, "ply\nformat binary_little_endian 1.0\ncomment synthetic ganesha-like mesh\nelement vertex %zu\nproperty float x\nproperty float y\nproperty float z\nelement face %zu\nproperty list uint8 int vertex_indices\nend_header\n", X.size(), tri.size() / 3);
+  for (size_t i = 0; i < X.size(); ++i) {
+    const float v[3] = {(float)X[i], (float)Y[i], (float)Z[i]};
+    std::fwrite(v, 4, 3, f);
+  }
+  for (size_t t = 0; t + 2 < tri.size(); t += 3) {
+    const uint8_t n = 3;
+    std::fwrite(&n, 1, 1, f);
+    std::fwrite(&tri[t], 4, 3, f);
+  }
+  std::fclose(f);
+  return 0;
 }
 
 } // extern "C"

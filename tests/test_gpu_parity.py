@@ -253,3 +253,37 @@ def test_error_paths(P, oracle):
     with pytest.raises(P.PtxError):
         g_scene.trace_samples(8, 8, 1, 1, [9], [0], [0])
     g_scene.close()
+
+
+def test_cli_readme_command_reproduces_golden(P, tmp_path):
+    """The reference's README command line, run through the drop-in binary:
+    shirley_spheres --dimension=600,300 --samples-per-pixel=32 --max-ray-bounces=8 --no-progress"""
+    import os
+    import subprocess
+    from PIL import Image
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "path_tracer_ocaml_amd", "shirley_spheres")
+    out = str(tmp_path / "out.png")
+    env = dict(os.environ)
+    env["LD_LIBRARY_PATH"] = "/opt/rocm/lib:" + env.get("LD_LIBRARY_PATH", "")
+    res = subprocess.run([exe, "--dimension=600,300", "--samples-per-pixel=32", "--max-ray-bounces=8", "--no-progress",
+                          "-o", out], capture_output=True, text=True, env=env, timeout=300)
+    assert res.returncode == 0, res.stderr
+    # the reference's prints (shirley_spheres/bin/main.ml:254-267, render_command.ml:108)
+    for needle in ("dim = 600 x 300;", "#spheres = 530", "tree depth = 10", "build time = ", "leaf lengths =", "rendered in: "):
+        assert needle in res.stdout, res.stdout
+    got = np.array(Image.open(out).convert("RGB")).astype(np.int64)
+    golden = np.array(Image.open(os.path.join(root, "tests", "golden", "shirley-spheres.png")).convert("RGB")).astype(np.int64)
+    assert np.abs(got - golden).max() <= 1
+    assert (got != golden).mean() < 0.08  # only k/255-boundary bytes (the sky's blue channel) may differ
+
+
+def test_cli_rejects_bad_arguments(P):
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "path_tracer_ocaml_amd", "shirley_spheres")
+    env = dict(os.environ)
+    env["LD_LIBRARY_PATH"] = "/opt/rocm/lib:" + env.get("LD_LIBRARY_PATH", "")
+    assert subprocess.run([exe], capture_output=True, env=env).returncode == 124  # --dimension is required
+    assert subprocess.run([exe, "-d", "8,8", "--bogus"], capture_output=True, env=env).returncode == 124
