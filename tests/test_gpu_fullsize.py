@@ -1,0 +1,153 @@
+"""BASELINE.json's full-size configurations on the GPU, checked through size-independent properties
+(the oracle needs minutes per frame at these sizes):
+
+* determinism: two renders give bit-identical raw sums;
+* partition invariance: whole image == interleaved row bands of 2 / 5 ranks == any batch size (the sampler
+  offset depends only on the global (x, y, pass), integrator.ml:98);
+* a random subset of the frame's samples re-traced one by one is bit-identical to the oracle, and their sum
+  per pixel (in pass order) equals the frame's raw sum for fully covered pixels;
+* work counters are partition-invariant and match the oracle's on the sampled subset.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def P():
+    import path_tracer_ocaml_amd as P
+    assert P.lib().ptx_device_count() >= 1, P.last_error()
+    return P
+
+
+def _raw(P, torch, scene, w, h, spp, depth, **kw):
+    params = P.render_params(w, h, spp, depth, **kw)
+    rows = P.local_rows(params)
+    t = torch.zeros((rows, w, 3), dtype=torch.float64, device="cuda:0")
+    st = scene.render_raw_device(params, t.data_ptr())
+    return t, st, params
+
+
+def _assemble(P, torch, scene, w, h, spp, depth, world, **kw):
+    full = torch.zeros((h, w, 3), dtype=torch.float64, device="cuda:0")
+    tot = {"segments": 0, "nodes_tested": 0, "prims_tested": 0, "floor_tested": 0}
+    for rank in range(world):
+        part, st, params = _raw(P, torch, scene, w, h, spp, depth, band_rows=32, band_first=rank, band_step=world, **kw)
+        idx = torch.as_tensor([P.global_row(params, k) for k in range(part.shape[0])], device="cuda:0")
+        full[idx] = part
+        for k in tot:
+            tot[k] += st[k]
+    return full, tot
+
+
+def test_config2_shirley_1080p_spp64(P, oracle):
+    torch = pytest.importorskip("torch")
+    from path_tracer_ocaml_amd import host as H
+    w, h, spp, depth = 1920, 1080, 64, 8
+    hs = H.shirley_spheres(w, h)
+    scene = P.Scene(hs.ptr, 0, keepalive=hs)
+    a, st_a, _ = _raw(P, torch, scene, w, h, spp, depth, count_work=True)
+    b, _, _ = _raw(P, torch, scene, w, h, spp, depth)
+    assert torch.equal(a.view(torch.int64), b.view(torch.int64)), "two renders differ"
+    c, _, _ = _raw(P, torch, scene, w, h, spp, depth, passes_per_batch=5)  # 13 ragged batches
+    assert torch.equal(a.view(torch.int64), c.view(torch.int64)), "batch size changed the result"
+    d2, tot2 = _assemble(P, torch, scene, w, h, spp, depth, 2, count_work=True)
+    assert torch.equal(a.view(torch.int64), d2.view(torch.int64)), "2-rank band sharding changed the result"
+    d5, _ = _assemble(P, torch, scene, w, h, spp, depth, 5)
+    assert torch.equal(a.view(torch.int64), d5.view(torch.int64)), "5-rank band sharding changed the result"
+    for k in ("segments", "nodes_tested", "prims_tested"):
+        assert tot2[k] == st_a[k], k
+    assert st_a["samples"] == w * h * spp
+    # oracle on a sample of the frame's own samples: whole pixels (all 64 passes) so sums can be compared
+    rng = np.random.default_rng(5)
+    px = rng.integers(0, w, 300)
+    py = rng.integers(0, h, 300)
+    xs = np.repeat(px, spp)
+    ys = np.repeat(py, spp)
+    ps = np.tile(np.arange(spp), 300)
+    od = oracle.desc_shirley(w, h)
+    o_rgb, o_ct = oracle.Scene(od.ptr, od).trace_samples(w, h, spp, depth, xs, ys, ps)
+    g_rgb, g_st = scene.trace_samples(w, h, spp, depth, xs, ys, ps, count_work=True)
+    assert np.array_equal(g_rgb.view(np.uint64), o_rgb.view(np.uint64))
+    for k in ("segments", "nodes_tested", "prims_tested"):
+        assert g_st[k] == o_ct[k]
+    raw = a.cpu().numpy()
+    sums = np.zeros((300, 3))
+    per = o_rgb.reshape(300, spp, 3)
+    for k in range(spp):  # pass order, like render_tile's pass loop
+        sums = sums + per[:, k, :]
+    assert np.array_equal(sums.view(np.uint64), raw[py, px].view(np.uint64)), "frame raw sums != oracle per-sample sums"
+    scene.close()
+
+
+def test_config3_cornell_1024_spp256_depth16(P, oracle):
+    torch = pytest.importorskip("torch")
+    from path_tracer_ocaml_amd import host as H
+    w, h, spp, depth = 1024, 1024, 256, 16
+    hs = H.cornell_box(w, h, 12.0)
+    scene = P.Scene(hs.ptr, 0, keepalive=hs)
+    a, _, _ = _raw(P, torch, scene, w, h, spp, depth)
+    d3, _ = _assemble(P, torch, scene, w, h, spp, depth, 3)
+    assert torch.equal(a.view(torch.int64), d3.view(torch.int64))
+    assert float(a.max()) > 0.0 and bool(torch.isfinite(a).all())
+    rng = np.random.default_rng(6)
+    n = 30000
+    xs, ys, ps = rng.integers(0, w, n), rng.integers(0, h, n), rng.integers(0, spp, n)
+    od = oracle.desc_cornell(w, h, 12.0)
+    o_rgb, o_ct = oracle.Scene(od.ptr, od).trace_samples(w, h, spp, depth, xs, ys, ps)
+    g_rgb, g_st = scene.trace_samples(w, h, spp, depth, xs, ys, ps, count_work=True)
+    assert np.array_equal(g_rgb.view(np.uint64), o_rgb.view(np.uint64))
+    assert g_st["nodes_tested"] == o_ct["nodes_tested"] and g_st["prims_tested"] == o_ct["prims_tested"]
+    scene.close()
+
+
+def test_config4_ganesha_like_150k_triangles(P, oracle):
+    torch = pytest.importorskip("torch")
+    from path_tracer_ocaml_amd import host as H
+    w, h, spp, depth = 1920, 1080, 64, 8
+    hs = H.ganesha_like(w, h, 150000, 7)
+    scene = P.Scene(hs.ptr, 0, keepalive=hs)
+    assert scene.stats()["tree_nodes"] > 80000
+    a, _, _ = _raw(P, torch, scene, w, h, spp, depth)
+    d4, _ = _assemble(P, torch, scene, w, h, spp, depth, 4)
+    assert torch.equal(a.view(torch.int64), d4.view(torch.int64))
+    rng = np.random.default_rng(7)
+    n = 30000
+    xs, ys, ps = rng.integers(0, w, n), rng.integers(0, h, n), rng.integers(0, spp, n)
+    od = oracle.desc_ganesha_like(w, h, 150000, 7)
+    o_rgb, o_ct = oracle.Scene(od.ptr, od).trace_samples(w, h, spp, depth, xs, ys, ps)
+    g_rgb, g_st = scene.trace_samples(w, h, spp, depth, xs, ys, ps, count_work=True)
+    assert np.array_equal(g_rgb.view(np.uint64), o_rgb.view(np.uint64))
+    for k in ("segments", "nodes_tested", "prims_tested", "floor_tested"):
+        assert g_st[k] == o_ct[k], k
+    scene.close()
+
+
+def test_config5_shirley_4k_rows_of_one_rank_of_eight(P, oracle):
+    """3840x2160 spp=256 is 2.1 G samples; one rank of an 8-rank job renders 1/8 of the rows.  Check that rank's
+    rows against the oracle on sampled pixels and against a differently batched render."""
+    torch = pytest.importorskip("torch")
+    from path_tracer_ocaml_amd import host as H
+    w, h, spp, depth = 3840, 2160, 256, 8
+    hs = H.shirley_spheres(w, h)
+    scene = P.Scene(hs.ptr, 0, keepalive=hs)
+    part, st, params = _raw(P, torch, scene, w, h, spp, depth, band_rows=32, band_first=3, band_step=8)
+    rows = part.shape[0]
+    assert st["samples"] == rows * w * spp
+    part2, _, _ = _raw(P, torch, scene, w, h, spp, depth, band_rows=32, band_first=3, band_step=8, passes_per_batch=7)
+    assert torch.equal(part.view(torch.int64), part2.view(torch.int64))
+    rng = np.random.default_rng(8)
+    lr = rng.integers(0, rows, 40)
+    px = rng.integers(0, w, 40)
+    gy = np.array([P.global_row(params, int(k)) for k in lr])
+    xs, ys, ps = np.repeat(px, spp), np.repeat(gy, spp), np.tile(np.arange(spp), 40)
+    od = oracle.desc_shirley(w, h)
+    o_rgb, _ = oracle.Scene(od.ptr, od).trace_samples(w, h, spp, depth, xs, ys, ps)
+    per = o_rgb.reshape(40, spp, 3)
+    sums = np.zeros((40, 3))
+    for k in range(spp):
+        sums = sums + per[:, k, :]
+    got = part.cpu().numpy()[lr, px]
+    assert np.array_equal(sums.view(np.uint64), got.view(np.uint64))
+    scene.close()
