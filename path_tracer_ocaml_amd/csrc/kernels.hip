@@ -212,9 +212,14 @@ __device__ __forceinline__ V3 pt_primary_dir(const PtSceneDev& sc, const PtGenPa
 /* Bbox.is_hit when no 0 * inf can occur (every 1/d component finite): no NaN is ever produced, so Base's
  * NaN-propagating min/max coincide with the hardware v_min_f64 / v_max_f64 -- same boolean, 4x fewer
  * instructions.  (The values may differ in the sign of a zero, which no comparison can see.) */
+template <bool ORIGIN_ZERO>
 __device__ __forceinline__ bool pt_slab_hit_fast(const double* nb, V3 o, V3 inv, double t_min, double t_max) {
-  const double t0x = (nb[0] - o.x) * inv.x, t0y = (nb[1] - o.y) * inv.y, t0z = (nb[2] - o.z) * inv.z;
-  const double t1x = (nb[3] - o.x) * inv.x, t1y = (nb[4] - o.y) * inv.y, t1z = (nb[5] - o.z) * inv.z;
+  /* camera rays start at P3.origin = (+0, +0, +0): x - (+0.0) == x bit for bit (also for x = -0.0), so the six
+   * subtractions can be dropped for them */
+  const double t0x = (ORIGIN_ZERO ? nb[0] : nb[0] - o.x) * inv.x, t0y = (ORIGIN_ZERO ? nb[1] : nb[1] - o.y) * inv.y,
+               t0z = (ORIGIN_ZERO ? nb[2] : nb[2] - o.z) * inv.z;
+  const double t1x = (ORIGIN_ZERO ? nb[3] : nb[3] - o.x) * inv.x, t1y = (ORIGIN_ZERO ? nb[4] : nb[4] - o.y) * inv.y,
+               t1z = (ORIGIN_ZERO ? nb[5] : nb[5] - o.z) * inv.z;
   const double a = __builtin_fmax(__builtin_fmin(t0x, t1x), __builtin_fmax(__builtin_fmin(t0y, t1y), __builtin_fmin(t0z, t1z)));
   const double b = __builtin_fmin(__builtin_fmax(t0x, t1x), __builtin_fmin(__builtin_fmax(t0y, t1y), __builtin_fmax(t0z, t1z)));
   return __builtin_fmax(t_min, a) <= __builtin_fmin(t_max, b);
@@ -250,7 +255,7 @@ struct PtTraceResult {
 #define PT_WALK_MIN 8
 #endif
 
-template <int MODE, bool COUNT, typename StackT>
+template <int MODE, bool COUNT, bool ORIGIN_ZERO, typename StackT>
 __device__ __forceinline__ PtTraceResult pt_trace_ray(const PtSceneDev& sc, const PtSceneView& sv, StackT* stack,
                                                       V3 o, V3 d, unsigned long long& c_nodes,
                                                       unsigned long long& c_prims, unsigned long long& c_floor) {
@@ -310,7 +315,7 @@ __device__ __forceinline__ PtTraceResult pt_trace_ray(const PtSceneDev& sc, cons
       const PtNode* np = sv.nodes + node;
       if (COUNT) c_nodes++;
       bool descend = false;
-      const bool hit = exact_slab ? pt_slab_hit_exact(np->mn, o, inv, t_min, r.t) : pt_slab_hit_fast(np->mn, o, inv, t_min, r.t);
+      const bool hit = exact_slab ? pt_slab_hit_exact(np->mn, o, inv, t_min, r.t) : pt_slab_hit_fast<ORIGIN_ZERO>(np->mn, o, inv, t_min, r.t);
       if (hit) {
         const uint32_t na = np->a, nb = np->b;
         const uint32_t axis = nb >> 30;
@@ -351,7 +356,8 @@ __device__ __forceinline__ PtTraceResult pt_trace_ray(const PtSceneDev& sc, cons
           bool found = false;
           while (k < leaf_n && !found) {
             const double* s = sv.sph + (size_t)(leaf_first + k) * 4;
-            const double fx = s[0] - o.x, fy = s[1] - o.y, fz = s[2] - o.z;
+            const double fx = ORIGIN_ZERO ? s[0] : s[0] - o.x, fy = ORIGIN_ZERO ? s[1] : s[1] - o.y,
+                         fz = ORIGIN_ZERO ? s[2] : s[2] - o.z; /* f = center - origin */
             const double r2 = s[3] * s[3];
             c = pt_fma(fx, fx, pt_fma(fy, fy, fz * fz)) - r2;
             bp = pt_fma(fx, d.x, pt_fma(fy, d.y, fz * d.z));
@@ -480,7 +486,7 @@ __global__ __launch_bounds__(LDS_SCENE ? 1024 : 512) void k_trace(PtSceneDev sc,
       d = v3(q.dx[i], q.dy[i], q.dz[i]);
     }
     if (COUNT) c_seg++;
-    const PtTraceResult r = pt_trace_ray<MODE, COUNT, StackT>(sc, sv, stack, o, d, c_nodes, c_prims, c_floor);
+    const PtTraceResult r = pt_trace_ray<MODE, COUNT, PRIMARY, StackT>(sc, sv, stack, o, d, c_nodes, c_prims, c_floor);
     hits.t[i] = r.t;
     hits.slot[i] = r.slot;
     if (MODE == PT_MODE_ARRAY && sc.has_triangles) {

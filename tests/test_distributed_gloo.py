@@ -69,3 +69,6 @@ def test_band_layout_properties():
             assert sorted(allrows.tolist()) == list(range(h))
             # interleaving balances the load: no rank owns more than one band beyond its share
             assert max(len(r) for r in rows) - min(len(r) for r in rows) <= D.BAND_ROWS
+    # BASELINE config 2 on 8 ranks: the busiest rank is within 1 % of the mean
+    rows = D.band_layout(1080, 8)
+    assert max(len(r) for r in rows) <= 1.01 * 1080 / 8
