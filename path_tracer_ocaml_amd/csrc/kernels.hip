@@ -970,4 +970,5 @@ __global__ void k_load_rays(long long n, const double* __restrict__ o, const dou
   q.dx[i] = d[3 * i]; q.dy[i] = d[3 * i + 1]; q.dz[i] = d[3 * i + 2];
 }
 
+#include "bvh_build_gpu.inc"
 #include "ptx_api.inc"

@@ -287,3 +287,33 @@ def test_cli_rejects_bad_arguments(P):
     env["LD_LIBRARY_PATH"] = "/opt/rocm/lib:" + env.get("LD_LIBRARY_PATH", "")
     assert subprocess.run([exe], capture_output=True, env=env).returncode == 124  # --dimension is required
     assert subprocess.run([exe, "-d", "8,8", "--bogus"], capture_output=True, env=env).returncode == 124
+
+
+# ---------------------------------------------------------------- GPU BVH build
+def _force_builder(P, desc_ptr, which):
+    import ctypes as C
+    from path_tracer_ocaml_amd import abi
+    d = abi.SceneDesc()
+    C.memmove(C.byref(d), desc_ptr, C.sizeof(d))
+    d.reserved = which  # 1 host, 2 GPU
+    return d
+
+
+@pytest.mark.parametrize("name", ["shirley", "shirley_no_simd", "cornell", "ganesha_20k", "ganesha_150k"])
+def test_gpu_bvh_build_equals_oracle_tree(P, oracle, name):
+    """Shape_tree.create on the GPU (level-synchronous binned SAH + exact Hoare-partition emulation): the same
+    tree, boxes bit for bit, and the same element order inside every leaf as the oracle's recursive builder."""
+    od = {"shirley": lambda: oracle.desc_shirley(600, 300), "shirley_no_simd": lambda: oracle.desc_shirley(600, 300, no_simd=True),
+          "cornell": lambda: oracle.desc_cornell(256, 256), "ganesha_20k": lambda: oracle.desc_ganesha_like(192, 108, 20000),
+          "ganesha_150k": lambda: oracle.desc_ganesha_like(1920, 1080, 150000)}[name]()
+    ob, oi, oo = oracle.Scene(od.ptr, od).tree()
+    g = P.Scene(_force_builder(P, od.ptr, 2), 0, keepalive=od)
+    gb, gi, go = g.tree()
+    assert np.array_equal(bits(gb), bits(ob)), "node boxes differ"
+    assert np.array_equal(gi, oi), "tree structure differs"
+    assert np.array_equal(go, oo), "leaf element order differs"
+    h = P.Scene(_force_builder(P, od.ptr, 1), 0, keepalive=od)
+    assert g.stats()["tree_depth"] == h.stats()["tree_depth"]
+    print(name, "build ms: gpu %.2f host %.2f" % (g.stats()["build_ms"], h.stats()["build_ms"]))
+    g.close()
+    h.close()
