@@ -52,6 +52,25 @@ def algorithmic_bytes(stats, spp, triangles):
     return total, trace_only
 
 
+def measured_hbm_copy_gbs(torch, dev):
+    """Measured device copy bandwidth (read + write bytes / time) of a 1 GiB f32 tensor: the 'measured HBM
+    roofline' BASELINE.md asks for next to the 8 TB/s datasheet figure."""
+    n = 1 << 28
+    a = torch.empty(n, dtype=torch.float32, device=dev).normal_()
+    b = torch.empty_like(a)
+    for _ in range(2):
+        b.copy_(a)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    reps = 10
+    for _ in range(reps):
+        b.copy_(a)
+    e1.record()
+    torch.cuda.synchronize()
+    return 2.0 * a.numel() * 4 * reps / (e0.elapsed_time(e1) * 1e-3) * 1e-9
+
+
 def cpu_baseline(workload, seconds_budget=20.0):
     """The oracle (C restatement of the reference CPU path, libm math like the OCaml runtime, tile-parallel
     over all host threads like integrator.ml:138-146) timed on a bounded sample of the same workload."""
@@ -196,6 +215,10 @@ def main():
                 traffic = json.load(open(tpath)).get(args.workload, {}).get("trace_hbm_bytes_per_launch")
             except Exception:
                 traffic = None
+        try:
+            copy_gbs = measured_hbm_copy_gbs(torch, dev)
+        except Exception:
+            copy_gbs = None
         out = {
             "metric": "Msamples/s (WxHxspp) + achieved HBM GB/s vs roofline; per-pixel Linf vs CPU ref",
             "value": value, "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -209,6 +232,7 @@ def main():
                 # N ranks: whole-job bytes over the slowest rank's kernel time, against N GPUs' HBM
                 "bound": "hbm", "kernel": "k_trace", "achieved": achieved, "peak": HBM_PEAK_GBS * world, "unit": "GB/s",
                 "frac": achieved / (HBM_PEAK_GBS * world), "traffic": traffic,
+                "peak_measured_copy": copy_gbs, "frac_of_measured": (achieved / (copy_gbs * world)) if copy_gbs else None,
                 "algorithmic_bytes_per_launch": b_trace / max(trace_launches / args.steps, 1.0),
                 "launches_per_step": trace_launches / args.steps, "avg_launch_ms": trace_ms_total / max(trace_launches, 1.0),
                 "pipeline": {"bytes_per_sample": b_total / samples, "achieved": b_total * args.steps / elapsed * 1e-9,

@@ -691,8 +691,11 @@ template <bool EMIT, bool PRIMARY>
 __global__ __launch_bounds__(512, 4) void k_shade(PtSceneDev sc, PtQueue q, PtHits hits, PtQueue out, PtContrib contrib,
                                                 const double* __restrict__ alpha, int bounce, int last_bounce,
                                                 PtGenParams g, uint32_t n_primary) {
-  __shared__ uint32_t lds_append[17];
+#if PT_APPEND_BINS > 1
   __shared__ uint32_t lds_bins[65];
+#else
+  __shared__ uint32_t lds_append[17];
+#endif
   __shared__ uint32_t lds_cnt[PT_N_CAT * 8];
   __shared__ uint16_t lds_perm[512];
   const uint32_t n = PRIMARY ? n_primary : *q.count;
