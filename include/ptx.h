@@ -164,6 +164,38 @@ typedef struct ptx_stats {
   double build_ms; /* host BVH build + upload at ptx_scene_create */
 } ptx_stats;
 
+/* ---- progressive photon mapping (progressive-photon-map/src/progressive_photon_map.ml) ---- */
+#define PTX_LIGHT_POINT 0 /* Light.create_point ~position ~power ~color  (:64-84) */
+#define PTX_LIGHT_SPOT 1  /* Light.create_spot ~position ~direction ~color ~power (:86-110) */
+
+typedef struct ptx_light {
+  int32_t kind;
+  int32_t reserved;
+  double position[3];  /* camera space, like every other coordinate */
+  double direction[3]; /* spot only (not normalised by the caller) */
+  double color[3];     /* BEFORE the power scaling */
+  double power;
+} ptx_light;
+
+/* Progressive_photon_map.Args.t (:7-16) */
+typedef struct ptx_ppm_params {
+  int32_t width, height;
+  int32_t iterations;   /* default 10 */
+  int32_t max_bounces;  /* default 4 */
+  int32_t photon_count; /* default 75000 */
+  int32_t reserved;
+  double alpha;         /* default 2/3 */
+} ptx_ppm_params;
+
+typedef struct ptx_ppm_stats {
+  int64_t photons_stored;  /* Photon_map.length summed over iterations */
+  int64_t photon_rays;     /* segments traced from the lights */
+  int64_t eye_rays;        /* segments traced from the camera */
+  int64_t neighbors;       /* photons accepted by the radiance estimates */
+  double photon_ms, build_ms, gather_ms, total_ms;
+  double last_radius;
+} ptx_ppm_stats;
+
 typedef struct ptx_scene ptx_scene; /* opaque */
 
 typedef void (*ptx_progress_fn)(void* user, int64_t pixels_done);
@@ -226,6 +258,16 @@ int32_t ptx_trace_samples(ptx_scene* scene, const ptx_render_params* params, int
 int32_t ptx_intersect_rays(ptx_scene* scene, int64_t n, const double* origins,
                            const double* directions, double* t_out, int32_t* prim_out,
                            ptx_stats* stats);
+
+/* Replaces Progressive_photon_map.Make(Scene).go (:420-451) up to, but not including, the per-iteration
+ * gamma + PNG write: img_sum_out (HOST, width*height*3, row 0 = top as Bimage stores it) receives the
+ * reference's img_sum after `iterations` iterations, i.e. the sum over iterations of estimate / photon_count.
+ * Scene.bbox is the bounding box of the scene's tree; the eye pass and the photon pass use the scene's camera.
+ * iteration_cb (optional) is called on the calling thread after every iteration with the running img_sum. */
+typedef void (*ptx_ppm_iteration_fn)(void* user, int32_t iteration, double radius, int64_t photon_map_length,
+                                     const double* img_sum);
+int32_t ptx_ppm_render(ptx_scene* scene, const ptx_ppm_params* params, const ptx_light* lights, int32_t n_lights,
+                       double* img_sum_out, ptx_ppm_stats* stats, ptx_ppm_iteration_fn iteration_cb, void* user);
 
 /* Flattened tree, for inspection / parity of the builder: returns the node count and,
  * if the pointers are non-NULL, copies per node: bbox (6 doubles: min xyz, max xyz),

@@ -75,6 +75,9 @@ def lib():
     L.orc_intersect_rays.argtypes = [C.c_void_p, C.c_int64, dp, dp, dp, ip, C.POINTER(C.c_int64)]
     L.orc_render.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, dp, dp, C.POINTER(C.c_int64), dp]
     L.orc_set_math.argtypes = [C.c_int]
+    L.orc_ppm_render.argtypes = [C.c_void_p, C.POINTER(abi.PpmParams), C.POINTER(abi.Light), C.c_int, dp, C.POINTER(C.c_int64), dp]
+    L.orc_lights_cornell.argtypes = [C.c_int, C.c_int, C.POINTER(abi.Light)]
+    L.orc_lights_ganesha.argtypes = [C.c_void_p, C.POINTER(abi.Light)]
     _LIB = L
     return L
 
@@ -226,6 +229,23 @@ class Scene:
             out["counters"] = dict(zip(COUNTER_NAMES, [int(c) for c in ct]))
         return out
 
+    def ppm_render(self, params, lights):
+        """Progressive_photon_map.Make(Scene).go without the gamma / PNG step: img_sum (H, W, 3), stats."""
+        arr = (abi.Light * len(lights))(*lights)
+        img = np.zeros((params.height, params.width, 3))
+        st = (C.c_int64 * 4)()
+        radius = C.c_double()
+        rc = lib().orc_ppm_render(self._h, C.byref(params), arr, len(lights), _dp(img), st, C.byref(radius))
+        if rc != 0:
+            raise RuntimeError(f"orc_ppm_render failed: {rc}")
+        return img, {"photons_stored": int(st[0]), "photon_rays": int(st[1]), "eye_rays": int(st[2]), "neighbors": int(st[3]),
+                     "last_radius": radius.value}
+
+    def lights_ganesha(self):
+        out = (abi.Light * 2)()
+        n = lib().orc_lights_ganesha(self._h, out)
+        return [out[i] for i in range(n)]
+
     def close(self):
         if self._h:
             lib().orc_scene_destroy(self._h)
@@ -252,6 +272,12 @@ def lds_get_vec(n_dim, offsets, dims):
     lib().orc_lds_alpha(n_dim, _dp(alpha))
     x = 0.5 + alpha[np.asarray(dims)] * (1 + np.asarray(offsets)).astype(np.float64)
     return x - np.trunc(x)
+
+
+def lights_cornell(width, height):
+    out = (abi.Light * 1)()
+    n = lib().orc_lights_cornell(width, height, out)
+    return [out[i] for i in range(n)]
 
 
 def set_math(mode):

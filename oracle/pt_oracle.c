@@ -1780,4 +1780,273 @@ ORC_API void orc_debug_first_scatter(const orc_scene* sc, int width, int height,
   free(alpha);
 }
 
+/* ================================================================== progressive photon mapping
+ * progressive-photon-map/src/progressive_photon_map.ml -- the integrator the reference uses for cornell-box and
+ * ganesha.  No fixture of the reference pins this part: PARITY UNPINNED for PPM
+ * (the restatement is checked only for internal consistency and against the GPU). */
+typedef struct { sspace_t shader_space; v3 wi, flux; double radius; } photon_t; /* Photon.t, :112-130 */
+
+typedef struct {
+  int kind;
+  v3 position, color;  /* color already scaled by power */
+  sspace_t shader_space; /* spot */
+} light_t;
+
+static const double PPM_PI = 3.14159265358979323846;
+
+static light_t light_create(const ptx_light* l) {
+  light_t o; memset(&o, 0, sizeof o);
+  o.kind = l->kind;
+  o.position = v3_make(l->position[0], l->position[1], l->position[2]);
+  o.color = v3_scale(v3_make(l->color[0], l->color[1], l->color[2]), l->power); /* Color.scale color power */
+  if (l->kind == PTX_LIGHT_SPOT) /* Spot_light.create :91-95 */
+    o.shader_space = sspace_create(v3_normalize(v3_make(l->direction[0], l->direction[1], l->direction[2])), o.position);
+  return o;
+}
+static double light_power(const light_t* l) { return l->color.x + l->color.y + l->color.z; } /* :125-128 */
+
+/* Light.random_ray :112-118 */
+static ray_t light_random_ray(const light_t* l, double u, double v) {
+  if (l->kind == PTX_LIGHT_POINT) { /* Point_light.random_direction :69-78 */
+    double theta = 2.0 * PPM_PI * u;
+    double phi = m_acos(1.0 - (2.0 * v));
+    double sin_phi = m_sin(phi);
+    v3 dir = v3_make(sin_phi * m_cos(theta), sin_phi * m_sin(theta), m_cos(phi));
+    return ray_create(l->position, dir);
+  }
+  /* Spot_light.random_ray :97-105 ; angle = 0.5 * 45 * pi / 180 ; disk_radius = atan angle (:88-89) */
+  double angle = 0.5 * 45.0 * PPM_PI / 180.0;
+  double disk_radius = atan(angle);
+  double r = disk_radius * sqrt(u);
+  double theta = v * 2.0 * PPM_PI;
+  double x = r * m_cos(theta), y = r * m_sin(theta), z = 1.0;
+  return sspace_world_ray(&l->shader_space, v3_make(x, y, z));
+}
+
+typedef struct { photon_t* p; size_t n, cap; } photon_vec;
+static void pv_push(photon_vec* v, photon_t ph) {
+  if (v->n == v->cap) { v->cap = v->cap ? v->cap * 2 : 1024; v->p = (photon_t*)realloc(v->p, sizeof(photon_t) * v->cap); }
+  v->p[v->n++] = ph;
+}
+
+/* Photon_map.trace_photon :196-233 ; deposits appended in chronological order (the reference conses: reversed later) */
+static void trace_photon(const orc_scene* sc, const light_t* light, const double* alpha, int offset, int max_bounces, double radius,
+                         photon_vec* out, int64_t* rays) {
+  sampler_t smp; smp.alpha = alpha; smp.offset = offset;
+  double u = sample_dim(&smp, 0), v = sample_dim(&smp, 1);
+  ray_t ray = light_random_ray(light, u, v);
+  v3 flux = light->color;
+  int dim = 2;
+  while (max_bounces > 0) {
+    max_bounces = max_bounces - 1;
+    u = sample_dim(&smp, dim); v = sample_dim(&smp, dim + 1); /* take_2d BEFORE the intersection test */
+    dim = dim + 2;
+    hit_t h;
+    (*rays)++;
+    if (!scene_intersect(sc, &ray, &h, NULL, NULL, NULL)) return;
+    scatter_t s = hit_scatter(&sc->mt, &h, u);
+    if (s.kind == SC_ABSORB) return;
+    if (s.kind == SC_SPECULAR) { ray = s.ray; flux = v3_mul(flux, s.attenuation); continue; }
+    v3 color = s.attenuation;
+    flux = v3_mul(flux, color);
+    photon_t ph; /* Photon.create ss ray flux ~radius :123-126 */
+    ph.shader_space = h.shader_space;
+    ph.wi = v3_normalize(v3_neg(ray.direction));
+    ph.flux = flux;
+    ph.radius = radius;
+    pv_push(out, ph);
+    double color_max = v3_max_coord(color);
+    if (u <= color_max) {
+      double cm_inv = 1.0 / color_max;
+      flux = v3_scale(flux, cm_inv);
+      double u2 = u * cm_inv;
+      v3 dir = unit_square_to_hemisphere(u2, v);
+      ray = sspace_world_ray(&h.shader_space, dir);
+    } else return;
+  }
+}
+
+typedef struct { node_t* root; photon_t* photons; size_t n; orc_scene stub; } photon_map_t;
+
+/* Photon_map.create :235-256 */
+static photon_map_t photon_map_create(const orc_scene* sc, const double* alpha, int base, double radius, int photon_count, int max_bounces,
+                                      const light_t* lights, int n_lights, int64_t* rays) {
+  double total_power = 0.0;
+  for (int i = 0; i < n_lights; ++i) total_power = total_power + light_power(&lights[i]); /* List.sum: 0. + p1 + ... */
+  photon_vec chron; memset(&chron, 0, sizeof chron);
+  int offset = 0;
+  for (int li = 0; li < n_lights; ++li) {
+    double f = light_power(&lights[li]) / total_power;
+    int count = (int)((double)photon_count * f); /* Int.of_float truncates */
+    int start = offset;
+    offset = start + count;
+    for (int i = start; i < start + count; ++i) trace_photon(sc, &lights[li], alpha, i + base, max_bounces, radius, &chron, rays);
+  }
+  photon_map_t pm; memset(&pm, 0, sizeof pm);
+  pm.n = chron.n;
+  pm.photons = (photon_t*)malloc(sizeof(photon_t) * (chron.n + 1));
+  for (size_t i = 0; i < chron.n; ++i) pm.photons[i] = chron.p[chron.n - 1 - i]; /* the consed list */
+  free(chron.p);
+  if (pm.n == 0) return pm; /* "BUG: no photons" */
+  pm.stub.num_bins = 8; pm.stub.length_cutoff = 8; pm.stub.leaf_kind = PTX_LEAF_ARRAY;
+  bshape_t* bs = (bshape_t*)calloc(pm.n, sizeof(bshape_t));
+  for (size_t i = 0; i < pm.n; ++i) {
+    v3 c = pm.photons[i].shader_space.origin, r = v3_make(radius, radius, radius);
+    bs[i].shape.id = (int)i;
+    bs[i].bbox.min = v3_sub(c, r); bs[i].bbox.max = v3_add(c, r);
+    bs[i].centroid = bbox_center(bs[i].bbox);
+  }
+  bbox_t bbox = bs[0].bbox;
+  for (size_t i = 1; i < pm.n; ++i) bbox = bbox_union(bbox, bs[i].bbox);
+  pm.root = tree_build(&pm.stub, bbox, bs, (int)pm.n);
+  free(bs);
+  return pm;
+}
+static void photon_map_free(photon_map_t* pm) { tree_free(pm->root); free(pm->photons); }
+
+typedef struct { int* idx; size_t n, cap; } int_vec;
+/* Tree.fold_neighbors (shape_tree.ml:222-231) + Photon_map.fold_neighbors (:188-194) + the caller's filter (:341-347):
+ * visit order lhs then rhs; accepted photons appended (the reference conses, so its list is this reversed) */
+static void fold_neighbors_rec(const photon_map_t* pm, const node_t* t, v3 point, v3 hit_normal, int_vec* acc) {
+  if (!bbox_mem(&t->bbox, point)) return;
+  if (t->is_leaf) {
+    for (int i = 0; i < t->n_elts; ++i) {
+      const photon_t* p = &pm->photons[t->elts[i].id];
+      v3 v = v3_sub(point, p->shader_space.origin);
+      if (v3_quadrance(v) < p->radius * p->radius) {
+        if (v3_dot(p->shader_space.normal, hit_normal) > 1e-3) {
+          if (acc->n == acc->cap) { acc->cap = acc->cap ? acc->cap * 2 : 256; acc->idx = (int*)realloc(acc->idx, sizeof(int) * acc->cap); }
+          acc->idx[acc->n++] = t->elts[i].id;
+        }
+      }
+    }
+    return;
+  }
+  fold_neighbors_rec(pm, t->lhs, point, hit_normal, acc);
+  fold_neighbors_rec(pm, t->rhs, point, hit_normal, acc);
+}
+
+/* estimate_color :316-372 */
+static v3 ppm_estimate(const orc_scene* sc, const photon_map_t* pm, const double* alpha, int offset, int x, int y, int width, int height,
+                       int max_bounces, int_vec* scratch, int64_t* rays, int64_t* n_neighbors) {
+  sampler_t smp; smp.alpha = alpha; smp.offset = offset;
+  double inv_widthf = 1.0 / (double)width, inv_heightf = 1.0 / (double)height;
+  double dx = sample_dim(&smp, 0), dy = sample_dim(&smp, 1);
+  double cx = inv_widthf * (dx + (double)x), cy = inv_heightf * (dy + (double)y);
+  ray_t ray = camera_ray(&sc->camera, cx, cy);
+  v3 beta = v3_make(1.0, 1.0, 1.0);
+  int dimension = 2;
+  const v3 black = v3_make(0.0, 0.0, 0.0);
+  for (;;) {
+    if (max_bounces <= 0) return black;
+    hit_t h;
+    (*rays)++;
+    if (!scene_intersect(sc, &ray, &h, NULL, NULL, NULL)) return black;
+    max_bounces = max_bounces - 1;
+    double u = sample_dim(&smp, dimension);
+    scatter_t s = hit_scatter(&sc->mt, &h, u);
+    if (s.kind == SC_ABSORB) return black;
+    if (s.kind == SC_SPECULAR) { beta = v3_mul(s.attenuation, beta); ray = s.ray; dimension = dimension + 1; continue; }
+    beta = v3_mul(s.attenuation, beta);
+    v3 hit_point = h.shader_space.origin, hit_normal = h.shader_space.normal;
+    scratch->n = 0;
+    if (pm->root) fold_neighbors_rec(pm, pm->root, hit_point, hit_normal, scratch);
+    if (scratch->n == 0) return black;
+    *n_neighbors += (int64_t)scratch->n;
+    const double k = 1.0;
+    double normalizer = 1.0 - (2.0 / (3.0 * k));
+    double radius = pm->photons[scratch->idx[scratch->n - 1]].radius; /* hd of the consed list = last accepted */
+    double area = PPM_PI * (radius * radius);
+    v3 flux = black;
+    for (size_t j = scratch->n; j-- > 0;) { /* List.fold over the consed list = reverse visit order */
+      const photon_t* p = &pm->photons[scratch->idx[j]];
+      double distance = sqrt(v3_quadrance(v3_sub(p->shader_space.origin, hit_point)));
+      double w = (1.0 - (distance / (k * radius))) / 1.0; /* weight / pdf, pdf = 1.0 */
+      flux = v3_add(flux, v3_scale(p->flux, w));
+    }
+    return v3_scale(v3_mul(beta, flux), 1.0 / (area * normalizer));
+  }
+}
+
+/* radius2 / radius :381-392 */
+static double ppm_radius2(int i, double alpha, double init_radius2) {
+  double product = 1.0;
+  for (int k = 1; k <= i - 1; ++k) { double kf = (double)k; product = product * (kf + alpha) / kf; }
+  return product * init_radius2 / (double)i;
+}
+
+/* Make(Scene).go :420-451 without the gamma / PNG step; img_sum_out W*H*3 (row 0 = top) */
+ORC_API int orc_ppm_render(const orc_scene* sc, const ptx_ppm_params* p, const ptx_light* lights_in, int n_lights, double* img_sum_out,
+                           int64_t* stats_out /* photons_stored, photon_rays, eye_rays, neighbors */, double* radius_out) {
+  int width = p->width, height = p->height, max_bounces = p->max_bounces;
+  if (!sc->root || n_lights <= 0) return -1;
+  light_t* lights = (light_t*)malloc(sizeof(light_t) * (size_t)n_lights);
+  for (int i = 0; i < n_lights; ++i) lights[i] = light_create(&lights_in[i]);
+  int pdim = 2 + 2 * max_bounces, edim = 2 + max_bounces;
+  double* p_alpha = (double*)malloc(sizeof(double) * (size_t)pdim);
+  double* e_alpha = (double*)malloc(sizeof(double) * (size_t)edim);
+  orc_lds_alpha(pdim, p_alpha);
+  orc_lds_alpha(edim, e_alpha);
+  /* init_radius2 :292-297 */
+  bbox_t bb = sc->root->bbox;
+  v3 ext = v3_sub(bb.max, bb.min);
+  double a = (ext.x + ext.y + ext.z) / 3.0;
+  double b = (double)(width + height) / (double)2;
+  double init_radius2 = (a / b) * (a / b);
+  double inv_photon_count = 1.0 / (double)p->photon_count;
+  memset(img_sum_out, 0, sizeof(double) * (size_t)width * height * 3);
+  int64_t st[4] = {0, 0, 0, 0};
+  int_vec scratch; memset(&scratch, 0, sizeof scratch);
+  double radius = 0.0;
+  for (int it = 0; it < p->iterations; ++it) {
+    radius = sqrt(ppm_radius2(it + 1, p->alpha, init_radius2));
+    photon_map_t pm = photon_map_create(sc, p_alpha, it * p->photon_count, radius, p->photon_count, max_bounces, lights, n_lights, &st[1]);
+    if (pm.n == 0) { photon_map_free(&pm); free(lights); free(p_alpha); free(e_alpha); free(scratch.idx); return -2; }
+    st[0] += (int64_t)pm.n;
+    int eye_sample_base = it * width * height;
+    for (int pixel = 0; pixel < width * height; ++pixel) { /* render_image :374-381 */
+      int x = pixel % width, y = pixel / width;
+      v3 c = ppm_estimate(sc, &pm, e_alpha, pixel + eye_sample_base, x, y, width, height, max_bounces, &scratch, &st[2], &st[3]);
+      v3 color = v3_scale(c, inv_photon_count);
+      int yy = height - 1 - y; /* write_pixel :305-313 */
+      double* px = &img_sum_out[((size_t)yy * width + x) * 3];
+      px[0] = color.x + px[0]; px[1] = color.y + px[1]; px[2] = color.z + px[2];
+    }
+    photon_map_free(&pm);
+  }
+  if (stats_out) memcpy(stats_out, st, sizeof st);
+  if (radius_out) *radius_out = radius;
+  free(lights); free(p_alpha); free(e_alpha); free(scratch.idx);
+  return 0;
+}
+
+/* lights of the two reference scenes, in camera space */
+ORC_API int orc_lights_cornell(int width, int height, ptx_light* out) { /* cornell-box/bin/main.ml:183,225-228 */
+  const double pi = 3.14159265358979323846;
+  double fov = (2.0 * atan(0.5)) * 180.0 / pi;
+  camera_t cam = camera_create(v3_make(0.5, 0.5, -1.0), v3_make(0.5, 0.5, 0.0), v3_make(0.0, 1.0, 0.0), (double)width / (double)height, fov);
+  v3 pos = camera_transform(&cam, v3_make(0.5, 0.82, 0.5));
+  memset(out, 0, sizeof *out);
+  out->kind = PTX_LIGHT_POINT; out->position[0] = pos.x; out->position[1] = pos.y; out->position[2] = pos.z;
+  out->color[0] = out->color[1] = out->color[2] = 1.0; out->power = 2.0;
+  return 1;
+}
+ORC_API int orc_lights_ganesha(const orc_scene* sc, ptx_light* out) { /* ganesha/bin/main.ml:267-282 */
+  bbox_t bbox = sc->root->bbox;
+  v3 center = bbox_center(bbox);
+  v3 v = v3_sub(bbox.max, center);
+  v3 position = v3_add(bbox.max, v3_add(v3_scale(v, 3.0), v3_scale(v3_make(0.0, 0.0, 1.0), -400.0)));
+  v3 direction = v3_sub(center, position);
+  memset(out, 0, 2 * sizeof *out);
+  out[0].kind = PTX_LIGHT_SPOT; out[0].power = 10000.0;
+  out[0].position[0] = position.x; out[0].position[1] = position.y; out[0].position[2] = position.z;
+  out[0].direction[0] = direction.x; out[0].direction[1] = direction.y; out[0].direction[2] = direction.z;
+  out[0].color[0] = out[0].color[1] = out[0].color[2] = 1.0;
+  out[1].kind = PTX_LIGHT_SPOT; out[1].power = 3000.0;
+  out[1].position[2] = 1.0; out[1].direction[2] = -1.0; /* ~-V3.unit_z */
+  out[1].direction[0] = -0.0; out[1].direction[1] = -0.0;
+  out[1].color[0] = out[1].color[1] = out[1].color[2] = 1.0;
+  return 2;
+}
+
 ORC_API int orc_abi_version(void) { return PTX_ABI_VERSION; }

@@ -67,3 +67,30 @@ class Stats(C.Structure):
         ("tree_nodes", C.c_int32), ("tree_depth", C.c_int32), ("tree_leaves", C.c_int32), ("leaf_slots", C.c_int32),
         ("build_ms", C.c_double),
     ]
+
+
+PTX_LIGHT_POINT, PTX_LIGHT_SPOT = 0, 1
+
+
+class Light(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("reserved", C.c_int32), ("position", C.c_double * 3), ("direction", C.c_double * 3),
+                ("color", C.c_double * 3), ("power", C.c_double)]
+
+
+class PpmParams(C.Structure):
+    _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("iterations", C.c_int32), ("max_bounces", C.c_int32),
+                ("photon_count", C.c_int32), ("reserved", C.c_int32), ("alpha", C.c_double)]
+
+
+class PpmStats(C.Structure):
+    _fields_ = [("photons_stored", C.c_int64), ("photon_rays", C.c_int64), ("eye_rays", C.c_int64), ("neighbors", C.c_int64),
+                ("photon_ms", C.c_double), ("build_ms", C.c_double), ("gather_ms", C.c_double), ("total_ms", C.c_double),
+                ("last_radius", C.c_double)]
+
+
+def ppm_params(width=600, height=None, iterations=10, max_bounces=4, photon_count=75000, alpha=2.0 / 3.0):
+    """Defaults of Progressive_photon_map.Args.parse (progressive_photon_map.ml:17-54)."""
+    p = PpmParams()
+    p.width, p.height = width, width if height is None else height
+    p.iterations, p.max_bounces, p.photon_count, p.alpha = iterations, max_bounces, photon_count, alpha
+    return p

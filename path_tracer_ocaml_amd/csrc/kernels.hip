@@ -582,6 +582,109 @@ __device__ __forceinline__ V3 pt_background(const PtSceneDev& sc, V3 dir) {
                  v3(sc.bg_zenith[0], sc.bg_zenith[1], sc.bg_zenith[2]));
 }
 
+/* What Sphere.hit (sphere.ml:56-69) / Triangle.Hit.to_hit (triangle.ml:43-64) build: the local geometry of a hit
+ * and what Material.scatter's partial application captures. */
+struct PtSurface {
+  V3 point, normal; /* Shader_space.world_origin / world_normal */
+  Quat rot;         /* Shader_space.rotation */
+  V3 omega_i;       /* Shader_space.omega_i */
+  double tu, tv;    /* Texture.Coord */
+  bool hit_front;
+  PtMaterial m;
+};
+__device__ __forceinline__ PtSurface pt_surface_hit(const PtSceneDev& sc, V3 o, V3 d, int slot, double t_hit, double bu,
+                                                    double bv) {
+  const double pi = 3.14159265358979323846;
+  PtSurface sf;
+  sf.m = sc.materials[sc.slot_material[slot]];
+  sf.tu = 0.0;
+  sf.tv = 0.0;
+  const PtMaterial& m = sf.m;
+  const bool need_uv = (m.kind != 2) && (sc.textures[m.texture].kind != 0);
+  if (sc.slot_kind[slot] == PT_SLOT_SPHERE) {
+    /* Sphere.hit (sphere.ml:56-69) */
+    const double* s = sc.sph + (size_t)slot * 4;
+    const V3 center = v3(s[0], s[1], s[2]);
+    sf.point = v3_add(o, v3_scale(d, t_hit)); /* Ray.point_at, ray.ml:15 */
+    V3 normal = v3_normalize(v3_sub(sf.point, center));
+    sf.hit_front = v3_dot(d, normal) < 0.0;
+    if (!sf.hit_front) normal = v3_neg(normal);
+    sf.normal = normal;
+    if (need_uv) { /* tex_coord (sphere.ml:25-33) feeds Texture.eval only */
+      const double one_over_pi = 1.0 / pi, one_over_two_pi = 1.0 / (2.0 * pi);
+      const double theta = pt_acos(-normal.y);
+      const double phi = pi + pt_atan2(-normal.z, normal.x);
+      sf.tu = phi * one_over_two_pi;
+      sf.tv = theta * one_over_pi;
+    }
+  } else {
+    /* Triangle.Hit.to_hit (triangle.ml:43-64) */
+    const double* tvx = sc.tri + (size_t)slot * 10;
+    const V3 a = pt_load_v3(tvx), b = pt_load_v3(tvx + 3), c = pt_load_v3(tvx + 6);
+    const V3 g_normal = v3_normalize(v3_cross(v3_sub(b, a), v3_sub(c, a)));
+    const double u = bu, v = bv;
+    const double w = 1.0 - u - v;
+    sf.point = v3_add(v3_add(v3_scale(a, w), v3_scale(b, u)), v3_scale(c, v));
+    const double* uv = sc.tri_uv + (size_t)slot * 6;
+    sf.tu = (uv[0] * w) + (uv[2] * u) + (uv[4] * v);
+    sf.tv = (uv[1] * w) + (uv[3] * u) + (uv[5] * v);
+    sf.hit_front = v3_dot(d, g_normal) < 0.0;
+    sf.normal = sf.hit_front ? g_normal : v3_neg(g_normal);
+  }
+  sf.rot = pt_shader_rotation(sf.normal);
+  sf.omega_i = pt_quat_transform(sf.rot, v3_neg(d)); /* Shader_space.omega_i */
+  return sf;
+}
+
+/* Material.scatter applied to u (material.ml:22-57): kind 0 Absorb | 1 Specular (wo = shader-space direction of the
+ * scattered ray, attenuation) | 2 Diffuse (attenuation = the texture colour) */
+struct PtScatter {
+  int kind;
+  V3 attenuation, wo;
+};
+__device__ __forceinline__ PtScatter pt_material_scatter(const PtSceneDev& sc, const PtSurface& sf, double su) {
+  const PtMaterial& m = sf.m;
+  const V3 omega_i = sf.omega_i;
+  PtScatter r;
+  r.attenuation = v3(1.0, 1.0, 1.0);
+  r.wo = v3(0.0, 0.0, 0.0);
+  if (m.kind == 0) {
+    r.kind = 2;
+    r.attenuation = pt_texture_eval(sc.textures[m.texture], sf.tu, sf.tv);
+  } else if (m.kind == 1) {
+    const V3 omega_r = v3(-omega_i.x, -omega_i.y, omega_i.z); /* Shader_space.reflect */
+    if (omega_r.z <= 0.0) {
+      r.kind = 0;
+    } else {
+      r.kind = 1;
+      const V3 a = pt_texture_eval(sc.textures[m.texture], sf.tu, sf.tv);
+      const double sp5 = pt_pow5(1.0 - omega_i.z);
+      const V3 c = v3_scale(v3_sub(v3(1.0, 1.0, 1.0), a), sp5);
+      r.attenuation = v3_add(a, c);
+      r.wo = omega_r;
+    }
+  } else {
+    r.kind = 1;
+    const double index = m.index, index_inv = 1.0 / m.index;
+    const double wi_z = omega_i.z;
+    const double c = wi_z < 0.0 ? 0.0 : (1.0 < wi_z ? 1.0 : wi_z); /* Float.clamp_exn */
+    const double sn = pt_sqrt(1.0 - c * c);
+    const double refract_ratio = sf.hit_front ? index_inv : index;
+    /* Both candidate directions are cheap: evaluate them unconditionally and select.  (A divergent
+     * `a || f(x) > u` branch here was miscompiled by hipcc -O3 -- caught by the bit-exact sample test.) */
+    const bool reflect = (refract_ratio * sn > 1.0) || (pt_schlick(c, refract_ratio) > su);
+    /* Shader_space.refract (shader_space.ml:41-49) */
+    const double cc = pt_base_min(omega_i.z, 1.0);
+    const V3 perp = v3_scale(v3_sub(v3(0.0, 0.0, cc), omega_i), refract_ratio);
+    const V3 para = v3(0.0, 0.0, -pt_sqrt(pt_fabs(1.0 - v3_quadrance(perp))));
+    const V3 refr = v3_add(perp, para);
+    r.wo.x = reflect ? -omega_i.x : refr.x; /* Shader_space.reflect (shader_space.ml:34-39) */
+    r.wo.y = reflect ? -omega_i.y : refr.y;
+    r.wo.z = reflect ? omega_i.z : refr.z;
+  }
+  return r;
+}
+
 struct PtContrib {
   double *r, *g, *b;
 };
@@ -745,87 +848,19 @@ __global__ __launch_bounds__(512, 4) void k_shade(PtSceneDev sc, PtQueue q, PtHi
         result = v3_fma(attn0, pt_background(sc, d), emit0);
       } else {
         const double t_hit = hits.t[i];
-        const uint8_t kind = sc.slot_kind[slot];
-        const PtMaterial m = sc.materials[sc.slot_material[slot]];
-        V3 point, normal;
-        double tu = 0.0, tv = 0.0;
-        bool hit_front;
-        const bool need_uv = (m.kind != 2) && (sc.textures[m.texture].kind != 0);
-        if (kind == PT_SLOT_SPHERE) {
-          /* Sphere.hit (sphere.ml:56-69) */
-          const double* s = sc.sph + (size_t)slot * 4;
-          const V3 center = v3(s[0], s[1], s[2]);
-          point = v3_add(o, v3_scale(d, t_hit)); /* Ray.point_at, ray.ml:15 */
-          normal = v3_normalize(v3_sub(point, center));
-          hit_front = v3_dot(d, normal) < 0.0;
-          if (!hit_front) normal = v3_neg(normal);
-          if (need_uv) { /* tex_coord (sphere.ml:25-33) feeds Texture.eval only */
-            const double one_over_pi = 1.0 / pi, one_over_two_pi = 1.0 / (2.0 * pi);
-            const double theta = pt_acos(-normal.y);
-            const double phi = pi + pt_atan2(-normal.z, normal.x);
-            tu = phi * one_over_two_pi;
-            tv = theta * one_over_pi;
-          }
-        } else {
-          /* Triangle.Hit.to_hit (triangle.ml:43-64) */
-          const double* tvx = sc.tri + (size_t)slot * 10;
-          const V3 a = pt_load_v3(tvx), b = pt_load_v3(tvx + 3), c = pt_load_v3(tvx + 6);
-          const V3 g_normal = v3_normalize(v3_cross(v3_sub(b, a), v3_sub(c, a)));
-          const double u = hits.u[i], v = hits.v[i];
-          const double w = 1.0 - u - v;
-          point = v3_add(v3_add(v3_scale(a, w), v3_scale(b, u)), v3_scale(c, v));
-          const double* uv = sc.tri_uv + (size_t)slot * 6;
-          tu = (uv[0] * w) + (uv[2] * u) + (uv[4] * v);
-          tv = (uv[1] * w) + (uv[3] * u) + (uv[5] * v);
-          hit_front = v3_dot(d, g_normal) < 0.0;
-          normal = hit_front ? g_normal : v3_neg(g_normal);
-        }
-        const Quat rot = pt_shader_rotation(normal);
-        const Quat rot_inv = pt_quat_conj(rot);
-        const V3 omega_i = pt_quat_transform(rot, v3_neg(d)); /* Shader_space.omega_i */
+        const bool is_tri = sc.slot_kind[slot] != PT_SLOT_SPHERE;
+        const PtSurface sf = pt_surface_hit(sc, o, d, slot, t_hit, is_tri ? hits.u[i] : 0.0, is_tri ? hits.v[i] : 0.0);
+        const PtMaterial& m = sf.m;
+        const V3 point = sf.point;
+        const Quat rot_inv = pt_quat_conj(sf.rot);
         const V3 emit = EMIT ? v3(m.emit[0], m.emit[1], m.emit[2]) : v3(0.0, 0.0, 0.0);
         /* take_2d (), integrator.ml:20-28,39: dims 2+2k, 3+2k for the k-th hit */
         const double su = pt_lds_get(alpha, offset, 2 + 2 * bounce);
         const double sv = pt_lds_get(alpha, offset, 3 + 2 * bounce);
-
-        /* Material.scatter (material.ml:22-57) */
-        int sc_kind; /* 0 Absorb, 1 Specular, 2 Diffuse */
-        V3 attenuation = v3(1.0, 1.0, 1.0);
-        V3 wo = v3(0, 0, 0); /* shader-space direction of the scattered ray */
-        if (m.kind == 0) {
-          sc_kind = 2;
-          attenuation = pt_texture_eval(sc.textures[m.texture], tu, tv);
-        } else if (m.kind == 1) {
-          const V3 omega_r = v3(-omega_i.x, -omega_i.y, omega_i.z); /* Shader_space.reflect */
-          if (omega_r.z <= 0.0) {
-            sc_kind = 0;
-          } else {
-            sc_kind = 1;
-            const V3 a = pt_texture_eval(sc.textures[m.texture], tu, tv);
-            const double sp5 = pt_pow5(1.0 - omega_i.z);
-            const V3 c = v3_scale(v3_sub(v3(1.0, 1.0, 1.0), a), sp5);
-            attenuation = v3_add(a, c);
-            wo = omega_r;
-          }
-        } else {
-          sc_kind = 1;
-          const double index = m.index, index_inv = 1.0 / m.index;
-          const double wi_z = omega_i.z;
-          const double c = wi_z < 0.0 ? 0.0 : (1.0 < wi_z ? 1.0 : wi_z); /* Float.clamp_exn */
-          const double sn = pt_sqrt(1.0 - c * c);
-          const double refract_ratio = hit_front ? index_inv : index;
-          /* both candidate directions are cheap; evaluate them unconditionally and select, so the wave
-           * does not diverge on the reflect / refract decision */
-          const bool reflect = (refract_ratio * sn > 1.0) || (pt_schlick(c, refract_ratio) > su);
-          /* Shader_space.refract (shader_space.ml:41-49) */
-          const double cc = pt_base_min(omega_i.z, 1.0);
-          const V3 perp = v3_scale(v3_sub(v3(0.0, 0.0, cc), omega_i), refract_ratio);
-          const V3 para = v3(0.0, 0.0, -pt_sqrt(pt_fabs(1.0 - v3_quadrance(perp))));
-          const V3 refr = v3_add(perp, para);
-          wo.x = reflect ? -omega_i.x : refr.x; /* Shader_space.reflect (shader_space.ml:34-39) */
-          wo.y = reflect ? -omega_i.y : refr.y;
-          wo.z = reflect ? omega_i.z : refr.z;
-        }
+        const PtScatter scat = pt_material_scatter(sc, sf, su);
+        const int sc_kind = scat.kind;
+        V3 attenuation = scat.attenuation;
+        V3 wo = scat.wo;
 
         if (sc_kind == 0) {
           result = v3_fma(attn0, emit, emit0); /* Absorb, integrator.ml:41 */
