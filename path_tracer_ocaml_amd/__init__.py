@@ -32,7 +32,7 @@ EXPORTS = (
     "ptx_version", "ptx_leaf_size", "ptx_last_error", "ptx_device_count", "ptx_scene_create", "ptx_scene_destroy",
     "ptx_scene_stats", "ptx_render", "ptx_local_rows", "ptx_global_row", "ptx_render_raw_device",
     "ptx_film_resolve_device", "ptx_trace_samples", "ptx_intersect_rays", "ptx_scene_tree", "ptx_lds_sample",
-    "ptx_math_eval",
+    "ptx_math_eval", "ptx_ppm_render",
 )
 
 PROGRESS_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_int64)
@@ -74,6 +74,8 @@ def lib():
     L.ptx_scene_tree.argtypes = [C.c_void_p, dp, ip, C.c_int32, ip, C.c_int32]
     L.ptx_lds_sample.argtypes = [C.c_int32, C.c_int32, C.c_int64, ip, ip, dp]
     L.ptx_math_eval.argtypes = [C.c_int32, C.c_int32, C.c_int64, dp, dp, dp]
+    L.ptx_ppm_render.argtypes = [C.c_void_p, C.POINTER(abi.PpmParams), C.POINTER(abi.Light), C.c_int32, dp,
+                                 C.POINTER(abi.PpmStats), C.c_void_p, C.c_void_p]
     _LIB = L
     return L
 
@@ -177,6 +179,14 @@ class Scene:
         st = abi.Stats()
         _check(lib().ptx_intersect_rays(self._h, n, _dp(o), _dp(d), _dp(t), _ip(prim), C.byref(st)))
         return t, prim, stats_dict(st)
+
+    def ppm_render(self, params, lights):
+        """ptx_ppm_render: Progressive_photon_map.Make(Scene).go without the gamma / PNG step -> img_sum (H, W, 3)."""
+        arr = (abi.Light * len(lights))(*lights)
+        img = np.zeros((params.height, params.width, 3))
+        st = abi.PpmStats()
+        _check(lib().ptx_ppm_render(self._h, C.byref(params), arr, len(lights), _dp(img), C.byref(st), None, None))
+        return img, {f: getattr(st, f) for f, _ in abi.PpmStats._fields_}
 
     def close(self):
         if getattr(self, "_h", None):

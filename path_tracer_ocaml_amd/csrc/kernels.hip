@@ -531,7 +531,7 @@ __device__ __forceinline__ V3 pt_quat_transform(Quat t, V3 v) {
   return pt_quat_mul(pt_quat_mul(t, p), c).v;
 }
 /* Shader_space.create (shader_space.ml:11-23) + Quaternion.normalize (quaternion.ml:11-15) */
-__device__ __forceinline__ Quat pt_shader_rotation(V3 normal) {
+__host__ __device__ __forceinline__ Quat pt_shader_rotation(V3 normal) {
   const double epsilon = 1e-9;
   Quat q;
   if (normal.z > 1.0 - epsilon) {
@@ -1009,4 +1009,5 @@ __global__ void k_load_rays(long long n, const double* __restrict__ o, const dou
 }
 
 #include "bvh_build_gpu.inc"
+#include "ppm.inc"
 #include "ptx_api.inc"
