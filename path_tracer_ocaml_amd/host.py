@@ -13,7 +13,7 @@ _LIB = None
 
 EXPORTS = ("pth_scene_desc", "pth_scene_free", "pth_camera_create", "pth_scene_shirley", "pth_scene_cornell",
            "pth_scene_ganesha_like", "pth_write_png", "pth_last_error", "pth_ply_load", "pth_ply_free", "pth_ply_count",
-           "pth_ply_floats", "pth_ply_ints", "pth_ply_rows", "pth_scene_ganesha_ply", "pth_write_ganesha_like_ply")
+           "pth_ply_floats", "pth_ply_ints", "pth_ply_rows", "pth_scene_ganesha_ply", "pth_write_ganesha_like_ply", "pth_lights_cornell", "pth_lights_ganesha", "pth_ppm_gamma")
 
 
 def lib():
@@ -49,6 +49,9 @@ def lib():
         L.pth_scene_ganesha_ply.restype = C.c_void_p
         L.pth_scene_ganesha_ply.argtypes = [C.c_char_p, C.c_int32, C.c_int32]
         L.pth_write_ganesha_like_ply.argtypes = [C.c_char_p, C.c_int32, C.c_uint64]
+        L.pth_lights_cornell.argtypes = [C.c_int32, C.c_int32, C.POINTER(abi.Light)]
+        L.pth_lights_ganesha.argtypes = [C.c_void_p, C.POINTER(abi.Light)]
+        L.pth_ppm_gamma.argtypes = [abi.c_double_p, C.c_int64, C.c_int32, abi.c_double_p]
         _LIB = L
     return _LIB
 
@@ -197,3 +200,25 @@ def ganesha_ply(path, width, height):
 def write_ganesha_like_ply(path, n_target=150000, seed=7):
     if lib().pth_write_ganesha_like_ply(path.encode(), n_target, seed) != 0:
         raise IOError(path)
+
+
+def lights_cornell(width, height):
+    """cornell-box/bin/main.ml:225-228."""
+    out = (abi.Light * 1)()
+    n = lib().pth_lights_cornell(width, height, out)
+    return [out[i] for i in range(n)]
+
+
+def lights_ganesha(scene):
+    """ganesha/bin/main.ml:267-282, from the mesh's camera-space bounding box."""
+    out = (abi.Light * 2)()
+    n = lib().pth_lights_ganesha(scene._h, out)
+    return [out[i] for i in range(n)]
+
+
+def ppm_gamma(img_sum, n):
+    """save_image (progressive_photon_map.ml:398-410): (sum / n) ** (1 / 2.2)."""
+    a = np.ascontiguousarray(img_sum, dtype=np.float64)
+    out = np.zeros_like(a)
+    lib().pth_ppm_gamma(a.ctypes.data_as(abi.c_double_p), a.size, n, out.ctypes.data_as(abi.c_double_p))
+    return out

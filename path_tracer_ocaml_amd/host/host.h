@@ -27,6 +27,12 @@ pth_scene* pth_scene_cornell(int32_t width, int32_t height, double ceiling_emit)
 /* ganesha/bin/main.ml camera / floor / material over a synthetic mesh of ~n_target triangles */
 pth_scene* pth_scene_ganesha_like(int32_t width, int32_t height, int32_t n_target, uint64_t seed);
 
+/* lights of the photon-mapped scenes (camera space): cornell-box/bin/main.ml:225-228, ganesha/bin/main.ml:267-282 */
+int32_t pth_lights_cornell(int32_t width, int32_t height, ptx_light* out);      /* writes 1 */
+int32_t pth_lights_ganesha(pth_scene* ganesha_scene, ptx_light* out /* 2 */); /* writes 2 */
+/* save_image's gamma (progressive_photon_map.ml:398-410): avg = (sum / n) ** (1 / 2.2), in place into out */
+void pth_ppm_gamma(const double* img_sum, int64_t count, int32_t n, double* out);
+
 /* ---- PLY (ply_format/src/ply.ml) ---- */
 typedef struct pth_ply pth_ply;
 const char* pth_last_error(void);

@@ -515,4 +515,48 @@ int32_t pth_write_ganesha_like_ply(const char* path, int32_t n_target, uint64_t 
   return 0;
 }
 
+
+// Lights of the two photon-mapped reference scenes, in camera space.
+// cornell-box/bin/main.ml:183,225-228: one point light at Camera.transform camera (0.5, 0.82, 0.5), power 2, white
+int32_t pth_lights_cornell(int32_t width, int32_t height, ptx_light* out) {
+  const double fov = (2.0 * std::atan(0.5)) * 180.0 / kPi;
+  const Camera cam = camera_create(v3(0.5, 0.5, -1.0), v3(0.5, 0.5, 0.0), v3(0.0, 1.0, 0.0), (double)width / (double)height, fov);
+  const V3 pos = camera_transform(cam, v3(0.5, 0.82, 0.5));
+  *out = ptx_light{};
+  out->kind = PTX_LIGHT_POINT;
+  out->position[0] = pos.x; out->position[1] = pos.y; out->position[2] = pos.z;
+  out->color[0] = out->color[1] = out->color[2] = 1.0;
+  out->power = 2.0;
+  return 1;
+}
+// ganesha/bin/main.ml:267-282: two spot lights placed from the mesh's camera-space bounding box
+int32_t pth_lights_ganesha(pth_scene* s, ptx_light* out) {
+  if (!s || s->tm.empty()) return 0;
+  Box bb{};
+  for (size_t t = 0; t < s->tm.size(); ++t)
+    for (int k = 0; k < 3; ++k) {
+      const int vi = s->ti[3 * t + k];
+      Box pb;
+      pb.mn = pb.mx = v3(s->vx[(size_t)vi], s->vy[(size_t)vi], s->vz[(size_t)vi]);
+      bb = (t == 0 && k == 0) ? pb : box_union(bb, pb);
+    }
+  const V3 center = box_center(bb);
+  const V3 v = v3_sub(bb.mx, center);
+  const V3 position = v3_add(bb.mx, v3_add(v3_scale(v, 3.0), v3_scale(v3(0.0, 0.0, 1.0), -400.0)));
+  const V3 direction = v3_sub(center, position);
+  out[0] = ptx_light{};
+  out[0].kind = PTX_LIGHT_SPOT;
+  out[0].power = 10000.0;
+  out[0].position[0] = position.x; out[0].position[1] = position.y; out[0].position[2] = position.z;
+  out[0].direction[0] = direction.x; out[0].direction[1] = direction.y; out[0].direction[2] = direction.z;
+  out[0].color[0] = out[0].color[1] = out[0].color[2] = 1.0;
+  out[1] = ptx_light{};
+  out[1].kind = PTX_LIGHT_SPOT;
+  out[1].power = 3000.0;
+  out[1].position[2] = 1.0;
+  out[1].direction[0] = -0.0; out[1].direction[1] = -0.0; out[1].direction[2] = -1.0; // ~-V3.unit_z
+  out[1].color[0] = out[1].color[1] = out[1].color[2] = 1.0;
+  return 2;
+}
+
 } // extern "C"

@@ -101,3 +101,23 @@ def test_png_writer_reproduces_golden(oracle, tmp_path):
     H.write_png(path, rgb)
     golden = np.array(Image.open(os.path.join(os.path.dirname(__file__), "golden", "shirley-spheres.png")).convert("RGB"))
     assert np.array_equal(np.array(Image.open(path).convert("RGB")), golden)
+
+
+def _light_bytes(l):
+    import ctypes as C
+    return bytes(C.string_at(C.byref(l), C.sizeof(l)))
+
+
+def test_ppm_lights_mirror(oracle):
+    """Lights of the photon-mapped scenes: host mirror == oracle restatement, byte for byte."""
+    from path_tracer_ocaml_amd import host as H
+    assert [_light_bytes(l) for l in H.lights_cornell(600, 600)] == [_light_bytes(l) for l in oracle.lights_cornell(600, 600)]
+    hs = H.ganesha_like(192, 108, 20000, 7)
+    od = oracle.desc_ganesha_like(192, 108, 20000, 7)
+    assert [_light_bytes(l) for l in H.lights_ganesha(hs)] == [_light_bytes(l) for l in oracle.Scene(od.ptr, od).lights_ganesha()]
+
+
+def test_ppm_gamma():
+    from path_tracer_ocaml_amd import host as H
+    a = np.array([[0.0, 0.5, 3.0]])
+    assert np.array_equal(H.ppm_gamma(a, 3), np.array([[0.0, (0.5 * (1.0 / 3)) ** (1.0 / 2.2), (3.0 * (1.0 / 3)) ** (1.0 / 2.2)]]))
