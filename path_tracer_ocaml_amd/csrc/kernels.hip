@@ -231,9 +231,17 @@ __device__ __forceinline__ bool pt_slab_hit_exact(const double* nb, V3 o, V3 inv
   return pt_slab_hit(n, o, inv, t_min, t_max);
 }
 
+/* LDS image of a node for the sign-selected slab test: per axis the triple (mn, mx, mn), so that the pair
+ * starting at +0 is (near, far) for a direction component > 0 and the pair starting at +8 bytes is (near, far) for a
+ * component < 0.  min(t0, t1) / max(t0, t1) of Bbox.hit_range are then known WITHOUT computing them: for 1/d > 0,
+ * (mn - o)*inv <= (mx - o)*inv because rounding is monotone, and the reverse for 1/d < 0 -- the same two values,
+ * six v_min/v_max_f64 fewer per node.  96 bytes: 9 bounds, a, b, n_real, pad. */
+#define PT_SWZ_NODE_BYTES 96
+
 /* where the traversal data of this launch lives: HBM/L2 (large scenes) or an LDS copy (small scenes) */
 struct PtSceneView {
   const PtNode* nodes;
+  const unsigned char* swz_nodes; /* LDS-resident scenes: PT_SWZ_NODE_BYTES per node */
   const double* sph;
   const double* tri;
   const uint8_t* kind;
@@ -255,7 +263,7 @@ struct PtTraceResult {
 #define PT_WALK_MIN 8
 #endif
 
-template <int MODE, bool COUNT, bool ORIGIN_ZERO, typename StackT>
+template <int MODE, bool COUNT, bool ORIGIN_ZERO, typename StackT, bool SWZ = false>
 __device__ __forceinline__ PtTraceResult pt_trace_ray(const PtSceneDev& sc, const PtSceneView& sv, StackT* stack,
                                                       V3 o, V3 d, unsigned long long& c_nodes,
                                                       unsigned long long& c_prims, unsigned long long& c_floor) {
@@ -263,6 +271,11 @@ __device__ __forceinline__ PtTraceResult pt_trace_ray(const PtSceneDev& sc, cons
   /* dirs, shape_tree.ml:201 */
   const uint32_t dirs = (d.x >= 0.0 ? 1u : 0u) | (d.y >= 0.0 ? 2u : 0u) | (d.z >= 0.0 ? 4u : 0u);
   const bool exact_slab = !(pt_isfinite(inv.x) && pt_isfinite(inv.y) && pt_isfinite(inv.z));
+  /* byte offsets of the (near, far) pair of each axis inside a swizzled LDS node */
+  uint3 swz_off;
+  swz_off.x = 0u + (inv.x < 0.0 ? 8u : 0u);
+  swz_off.y = 24u + (inv.y < 0.0 ? 8u : 0u);
+  swz_off.z = 48u + (inv.z < 0.0 ? 8u : 0u);
   const double t_min = 0.0;
   PtTraceResult r;
   r.t = PT_MAX_FINITE;
@@ -312,16 +325,45 @@ __device__ __forceinline__ PtTraceResult pt_trace_ray(const PtSceneDev& sc, cons
       if (wm == 0) break;
       if ((int)__popcll(wm) < PT_WALK_MIN && __ballot(leaf_n > 0) != 0) break;
       if (!want) continue;
-      const PtNode* np = sv.nodes + node;
       if (COUNT) c_nodes++;
       bool descend = false;
-      const bool hit = exact_slab ? pt_slab_hit_exact(np->mn, o, inv, t_min, r.t) : pt_slab_hit_fast<ORIGIN_ZERO>(np->mn, o, inv, t_min, r.t);
+      bool hit;
+      uint32_t na, nb, n_real;
+      if (SWZ) {
+        const unsigned char* nbase = sv.swz_nodes + (size_t)node * PT_SWZ_NODE_BYTES;
+        const uint2 links = *(const uint2*)(nbase + 72);
+        na = links.x;
+        nb = links.y;
+        n_real = *(const uint32_t*)(nbase + 80);
+        if (exact_slab) {
+          const double* bx = (const double*)nbase;
+          const double box6[6] = {bx[0], bx[3], bx[6], bx[1], bx[4], bx[7]};
+          hit = pt_slab_hit_exact(box6, o, inv, t_min, r.t);
+        } else {
+          /* (near, far) per axis, selected by the sign of the direction component through the load address */
+          /* 8-byte aligned pairs (ds_read2_b64): the +8 variants are not 16-byte aligned */
+          const double* px = (const double*)(nbase + swz_off.x);
+          const double* py = (const double*)(nbase + swz_off.y);
+          const double* pz = (const double*)(nbase + swz_off.z);
+          const double tnx = (ORIGIN_ZERO ? px[0] : px[0] - o.x) * inv.x, tfx = (ORIGIN_ZERO ? px[1] : px[1] - o.x) * inv.x;
+          const double tny = (ORIGIN_ZERO ? py[0] : py[0] - o.y) * inv.y, tfy = (ORIGIN_ZERO ? py[1] : py[1] - o.y) * inv.y;
+          const double tnz = (ORIGIN_ZERO ? pz[0] : pz[0] - o.z) * inv.z, tfz = (ORIGIN_ZERO ? pz[1] : pz[1] - o.z) * inv.z;
+          const double a = __builtin_fmax(tnx, __builtin_fmax(tny, tnz));
+          const double b = __builtin_fmin(tfx, __builtin_fmin(tfy, tfz));
+          hit = __builtin_fmax(t_min, a) <= __builtin_fmin(r.t, b);
+        }
+      } else {
+        const PtNode* np = sv.nodes + node;
+        hit = exact_slab ? pt_slab_hit_exact(np->mn, o, inv, t_min, r.t) : pt_slab_hit_fast<ORIGIN_ZERO>(np->mn, o, inv, t_min, r.t);
+        na = np->a;
+        nb = np->b;
+        n_real = np->pad[0];
+      }
       if (hit) {
-        const uint32_t na = np->a, nb = np->b;
         const uint32_t axis = nb >> 30;
         if (axis == PT_NODE_LEAF_AXIS) {
           leaf_first = (int)na;
-          leaf_n = (int)np->pad[0]; /* real slots; the NaN padding (main.ml:185) can never be selected */
+          leaf_n = (int)n_real; /* real slots; the NaN padding (main.ml:185) can never be selected */
           if (COUNT) c_prims += (unsigned long long)(nb & 0x3fffffffu); /* Leaf.length incl. padding */
         } else {
           /* Branch: near child first (shape_tree.ml:209), far child deferred */
@@ -429,24 +471,36 @@ __global__ __launch_bounds__(LDS_SCENE ? 1024 : 512) void k_trace(PtSceneDev sc,
   StackT* stack = (StackT*)lds_raw + (size_t)wave_in_block * stack_depth * PT_WAVE + lane;
   PtSceneView sv;
   sv.nodes = sc.nodes;
+  sv.swz_nodes = nullptr;
   sv.sph = sc.sph;
   sv.tri = sc.tri;
   sv.kind = sc.slot_kind;
   if (LDS_SCENE) {
     size_t off = ((size_t)waves_per_block * stack_depth * PT_WAVE * sizeof(StackT) + 63) & ~(size_t)63;
-    PtNode* l_nodes = (PtNode*)(lds_raw + off);
-    off += (size_t)sc.n_nodes * sizeof(PtNode);
+    unsigned char* l_nodes = lds_raw + off;
+    off += (size_t)sc.n_nodes * PT_SWZ_NODE_BYTES;
     const int total_slots = sc.n_slots + sc.n_floor;
     double* l_sph = (double*)(lds_raw + off);
     off += (size_t)total_slots * 4 * sizeof(double);
     double* l_tri = (double*)(lds_raw + off);
     if (MODE == PT_MODE_ARRAY && sc.has_triangles) off += (size_t)total_slots * 10 * sizeof(double);
     uint8_t* l_kind = (uint8_t*)(lds_raw + off);
-    /* cooperative copy, 16 bytes per thread per step */
-    {
-      const uint4* src = (const uint4*)sc.nodes;
-      uint4* dst = (uint4*)l_nodes;
-      for (int k = threadIdx.x; k < sc.n_nodes * 4; k += blockDim.x) dst[k] = src[k];
+    /* nodes: expanded to the swizzled image while they are copied */
+    for (int k = threadIdx.x; k < sc.n_nodes; k += blockDim.x) {
+      const PtNode* src = sc.nodes + k;
+      double* dst = (double*)(l_nodes + (size_t)k * PT_SWZ_NODE_BYTES);
+      for (int ax = 0; ax < 3; ++ax) {
+        dst[3 * ax] = src->mn[ax];
+        dst[3 * ax + 1] = src->mx[ax];
+        dst[3 * ax + 2] = src->mn[ax];
+      }
+      uint32_t* w = (uint32_t*)(dst + 9);
+      w[0] = src->a;
+      w[1] = src->b;
+      w[2] = src->pad[0];
+      w[3] = 0u;
+      w[4] = 0u;
+      w[5] = 0u;
     }
     {
       const uint4* src = (const uint4*)sc.sph;
@@ -462,7 +516,7 @@ __global__ __launch_bounds__(LDS_SCENE ? 1024 : 512) void k_trace(PtSceneDev sc,
       for (int k = threadIdx.x; k < total_slots; k += blockDim.x) l_kind[k] = sc.slot_kind[k];
     }
     __syncthreads();
-    sv.nodes = l_nodes;
+    sv.swz_nodes = l_nodes;
     sv.sph = l_sph;
     sv.tri = l_tri;
     sv.kind = l_kind;
@@ -486,7 +540,7 @@ __global__ __launch_bounds__(LDS_SCENE ? 1024 : 512) void k_trace(PtSceneDev sc,
       d = v3(q.dx[i], q.dy[i], q.dz[i]);
     }
     if (COUNT) c_seg++;
-    const PtTraceResult r = pt_trace_ray<MODE, COUNT, PRIMARY, StackT>(sc, sv, stack, o, d, c_nodes, c_prims, c_floor);
+    const PtTraceResult r = pt_trace_ray<MODE, COUNT, PRIMARY, StackT, LDS_SCENE>(sc, sv, stack, o, d, c_nodes, c_prims, c_floor);
     hits.t[i] = r.t;
     hits.slot[i] = r.slot;
     if (MODE == PT_MODE_ARRAY && sc.has_triangles) {
