@@ -28,6 +28,21 @@ def band_layout(height, world, band_rows=BAND_ROWS):
     return rows
 
 
+_INDEX_CACHE = {}
+
+
+def _row_index_tensors(height, world, band_rows, device):
+    """layout rows as device index tensors + padded row count, cached: the gather runs once per frame."""
+    import torch
+    key = (height, world, band_rows, str(device))
+    hit = _INDEX_CACHE.get(key)
+    if hit is None:
+        layout = band_layout(height, world, band_rows)
+        hit = ([torch.as_tensor(r, device=device) for r in layout], max(len(r) for r in layout), [len(r) for r in layout])
+        _INDEX_CACHE[key] = hit
+    return hit
+
+
 def max_local_rows(height, world, band_rows=BAND_ROWS):
     return max(len(r) for r in band_layout(height, world, band_rows))
 
@@ -40,12 +55,9 @@ def gather_raw_to_root(part, height, width, rank, world, band_rows=BAND_ROWS, gr
     import torch
     import torch.distributed as dist
 
-    layout = band_layout(height, world, band_rows)
+    index, pad, counts = _row_index_tensors(height, world, band_rows, part.device)
     if world == 1:
-        full = torch.empty((height, width, 3), dtype=part.dtype, device=part.device)
-        full[torch.as_tensor(layout[0], device=part.device)] = part
-        return full
-    pad = max(len(r) for r in layout)
+        return part  # one rank owns every row, in image order: nothing to move
     send = part
     if part.shape[0] != pad:
         send = torch.zeros((pad, width, 3), dtype=part.dtype, device=part.device)
@@ -61,6 +73,5 @@ def gather_raw_to_root(part, height, width, rank, world, band_rows=BAND_ROWS, gr
         return None
     full = torch.empty((height, width, 3), dtype=part.dtype, device=part.device)
     for r in range(world):
-        idx = torch.as_tensor(layout[r], device=part.device)
-        full[idx] = bufs[r][: len(layout[r])].to(part.device)
+        full[index[r]] = bufs[r][: counts[r]].to(part.device)
     return full
