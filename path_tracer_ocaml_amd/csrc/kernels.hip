@@ -458,8 +458,14 @@ __device__ __forceinline__ PtTraceResult pt_trace_ray(const PtSceneDev& sc, cons
  * LDS_SCENE: the whole tree and every leaf packet are first copied into LDS (small scenes: Shirley is
  * 22 KB of nodes + 22 KB of packets), so node / packet reads are ds_read_b128 instead of L1 traffic.
  * LDS layout: [traversal stacks: waves x depth x 64 u32][nodes][sphere slots][triangle slots][slot kinds] */
+#ifndef PT_TRACE_GLOBAL_WAVES
+#define PT_TRACE_GLOBAL_WAVES 4
+#endif
 template <int MODE, bool COUNT, bool PRIMARY, bool LDS_SCENE>
-__global__ __launch_bounds__(LDS_SCENE ? 1024 : 512) void k_trace(PtSceneDev sc, PtQueue q, PtHits hits, int stack_depth,
+/* Simd_leaf + LDS scene fits 64 VGPRs without spilling: ask for 2 x 1024-thread workgroups per CU.  The Array_leaf
+ * variants (triangle / scalar-sphere code) need ~100 VGPRs: forcing 64 would spill to scratch (1.5 GB of HBM
+ * writes per launch on cornell). */
+__global__ __launch_bounds__(LDS_SCENE ? 1024 : 512, (LDS_SCENE && MODE == PT_MODE_SIMD) ? 8 : PT_TRACE_GLOBAL_WAVES) void k_trace(PtSceneDev sc, PtQueue q, PtHits hits, int stack_depth,
                                                PtCounters* counters, PtGenParams g, const double* __restrict__ alpha,
                                                uint32_t n_primary) {
   extern __shared__ __attribute__((aligned(64))) unsigned char lds_raw[];

@@ -36,7 +36,8 @@ json.dump(pmc, open(os.path.join(dst, f"{tag}_pmc_hbm.json"), "w"), indent=1)
 def per_launch(counter, scale):
     n = tot = 0
     for k, v in pmc[counter].items():
-        if k.startswith("k_trace<") and ", false," in k.replace("<0, false", "<0, false,") and "k_trace<0, false" in k or k.startswith("k_trace<1, false"):
+        targs = k[k.index("<") + 1:].split(",") if k.startswith("k_trace<") else []
+        if len(targs) >= 2 and targs[1].strip() == "false":  # COUNT == false: the instantiations bench.py times
             n += v["launches"]
             tot += v["KB_total"]
     return tot / max(n, 1) * 1024.0 * scale
