@@ -262,219 +262,307 @@ struct PtTraceResult {
 #ifndef PT_WALK_MIN
 #define PT_WALK_MIN 8
 #endif
+/* PT_DIAG (diagnostic builds only, tools/diag_utilisation.sh): re-purposes the COUNT counters of SECONDARY launches
+ * to measure lane utilisation per traversal phase: nodes = useful lane steps, floor = lane slots the wave spent.
+ * 1: node walk   2: node walk if only the per-chunk tail were lost   3: packet scan   4: packet heavy part */
+#ifndef PT_DIAG
+#define PT_DIAG 0
+#endif
+#ifndef PT_PACKET_DEFER
+#define PT_PACKET_DEFER 1
+#endif
+#define PT_DIAG_WAVE_SLOTS(c) do { if (pt_lane() == __ffsll((long long)__ballot(1)) - 1) (c) += 64; } while (0)
 
+/* One ray's traversal state.  begin() = Ray.create + the per-ray constants; node_step() = one visit of
+ * Tree.intersect's recursion (shape_tree.ml:203-221); packet() = Leaf.intersect on the leaf the lane holds.
+ * pt_trace_ray drives it (one ray per lane, start to finish). */
+template <int MODE, bool COUNT, bool ORIGIN_ZERO, typename StackT, bool SWZ>
+struct PtTraverser {
+  V3 o, d, inv;
+  uint32_t dirs;
+  bool exact_slab;
+  uint3 swz_off; /* byte offsets of the (near, far) pair of each axis inside a swizzled LDS node */
+  double qa, one_over_a;
+  PtTraceResult r;
+  int sp;
+  uint32_t node;
+  bool walking;
+  int leaf_first, leaf_n;
+  __device__ __forceinline__ bool wants_node() const { return walking && leaf_n == 0; }
+
+  __device__ __forceinline__ void begin(const PtSceneDev& sc, const PtSceneView& sv, V3 o_, V3 d_,
+                                        unsigned long long& c_floor) {
+    o = o_;
+    d = d_;
+    inv = v3(1.0 / d.x, 1.0 / d.y, 1.0 / d.z); /* Ray.create, ray.ml:7-10 */
+    /* dirs, shape_tree.ml:201 */
+    dirs = (d.x >= 0.0 ? 1u : 0u) | (d.y >= 0.0 ? 2u : 0u) | (d.z >= 0.0 ? 4u : 0u);
+    exact_slab = !(pt_isfinite(inv.x) && pt_isfinite(inv.y) && pt_isfinite(inv.z));
+    swz_off.x = 0u + (inv.x < 0.0 ? 8u : 0u);
+    swz_off.y = 24u + (inv.y < 0.0 ? 8u : 0u);
+    swz_off.z = 48u + (inv.z < 0.0 ? 8u : 0u);
+    r.t = PT_MAX_FINITE;
+    r.slot = -1;
+    r.u = 0.0;
+    r.v = 0.0;
+    /* ganesha Floor.intersect (main.ml:247-256): f1 then f2, the first hit clips t_max for the tree */
+    if (MODE == PT_MODE_ARRAY && sc.n_floor > 0) {
+      for (int f = 0; f < sc.n_floor; ++f) {
+        const double* tv = sv.tri + (size_t)(sc.n_slots + f) * 10;
+        double t, u, v;
+        if (COUNT) c_floor++;
+        if (pt_triangle_intersect(pt_load_v3(tv), pt_load_v3(tv + 3), pt_load_v3(tv + 6), o, d, 0.0, PT_MAX_FINITE, &t,
+                                  &u, &v)) {
+          r.t = t;
+          r.u = u;
+          r.v = v;
+          r.slot = sc.n_slots + f;
+          break;
+        }
+      }
+    }
+    /* packet constants of spheres_intersect_aux (lib.rs:115-117): a is the UNFUSED scalar dot */
+    qa = 0.0;
+    one_over_a = 0.0;
+    if (MODE == PT_MODE_SIMD) {
+      qa = d.x * d.x + d.y * d.y + d.z * d.z;
+      one_over_a = 1.0 / qa;
+    }
+    sp = 0;
+    node = 0;
+    walking = sc.n_nodes > 0;
+    leaf_first = 0;
+    leaf_n = 0;
+  }
+
+  /* Visit `node`: bbox test against the closest hit so far, then descend / hold the leaf / pop.  The traversal
+   * stack (far children only) lives in LDS, one column per lane (conflict-free ds_write / ds_read).  A far child's
+   * bbox is tested when it is POPPED, against the closest hit so far -- exactly the t_max the reference's recursion
+   * passes (shape_tree.ml:210-216). */
+  __device__ __forceinline__ void node_step(const PtSceneView& sv, StackT* stack, unsigned long long& c_nodes,
+                                            unsigned long long& c_prims) {
+    const double t_min = 0.0;
+    if (COUNT && (PT_DIAG == 0 || (PT_DIAG <= 2 && !ORIGIN_ZERO))) c_nodes++;
+    bool descend = false;
+    bool hit;
+    uint32_t na, nb, n_real;
+    if (SWZ) {
+      const unsigned char* nbase = sv.swz_nodes + (size_t)node * PT_SWZ_NODE_BYTES;
+      const uint2 links = *(const uint2*)(nbase + 72);
+      na = links.x;
+      nb = links.y;
+      n_real = *(const uint32_t*)(nbase + 80);
+      if (exact_slab) {
+        const double* bx = (const double*)nbase;
+        const double box6[6] = {bx[0], bx[3], bx[6], bx[1], bx[4], bx[7]};
+        hit = pt_slab_hit_exact(box6, o, inv, t_min, r.t);
+      } else {
+        /* (near, far) per axis, selected by the sign of the direction component through the load address;
+         * 8-byte aligned pairs (ds_read2_b64): the +8 variants are not 16-byte aligned */
+        const double* px = (const double*)(nbase + swz_off.x);
+        const double* py = (const double*)(nbase + swz_off.y);
+        const double* pz = (const double*)(nbase + swz_off.z);
+        const double tnx = (ORIGIN_ZERO ? px[0] : px[0] - o.x) * inv.x, tfx = (ORIGIN_ZERO ? px[1] : px[1] - o.x) * inv.x;
+        const double tny = (ORIGIN_ZERO ? py[0] : py[0] - o.y) * inv.y, tfy = (ORIGIN_ZERO ? py[1] : py[1] - o.y) * inv.y;
+        const double tnz = (ORIGIN_ZERO ? pz[0] : pz[0] - o.z) * inv.z, tfz = (ORIGIN_ZERO ? pz[1] : pz[1] - o.z) * inv.z;
+        const double a = __builtin_fmax(tnx, __builtin_fmax(tny, tnz));
+        const double b = __builtin_fmin(tfx, __builtin_fmin(tfy, tfz));
+        hit = __builtin_fmax(t_min, a) <= __builtin_fmin(r.t, b);
+      }
+    } else {
+      const PtNode* np = sv.nodes + node;
+      hit = exact_slab ? pt_slab_hit_exact(np->mn, o, inv, t_min, r.t) : pt_slab_hit_fast<ORIGIN_ZERO>(np->mn, o, inv, t_min, r.t);
+      na = np->a;
+      nb = np->b;
+      n_real = np->pad[0];
+    }
+    if (hit) {
+      const uint32_t axis = nb >> 30;
+      if (axis == PT_NODE_LEAF_AXIS) {
+        leaf_first = (int)na;
+        leaf_n = (int)n_real; /* real slots; the NaN padding (main.ml:185) can never be selected */
+        if (COUNT && PT_DIAG == 0) c_prims += (unsigned long long)(nb & 0x3fffffffu); /* Leaf.length incl. padding */
+      } else {
+        /* Branch: near child first (shape_tree.ml:209), far child deferred */
+        const uint32_t lhs = na, rhs = nb & 0x3fffffffu;
+        const bool lhs_first = (dirs >> axis) & 1u;
+        PT_STACK_PUSH(stack, sp, lhs_first ? rhs : lhs);
+        ++sp;
+        node = lhs_first ? lhs : rhs;
+        descend = true;
+      }
+    }
+    if (!descend) {
+      /* the popped node's bbox is tested on the NEXT visit, i.e. after this leaf's packet has been
+       * intersected and r.t shrunk -- the t_max the reference passes to the far child */
+      if (sp == 0) walking = false;
+      else {
+        --sp;
+        node = PT_STACK_POP(stack, sp);
+      }
+    }
+  }
+
+  /* Leaf.intersect on the held leaf (caller checks leaf_n > 0) */
+  __device__ __forceinline__ void packet(const PtSceneView& sv, unsigned long long& c_nodes, unsigned long long& c_floor) {
+    const double t_min = 0.0;
+    if (MODE == PT_MODE_SIMD) {
+      /* spheres_intersect_aux, lib.rs:102-178, one packet lane per step, split in two so the wave stays
+       * dense: SCAN (cheap, every lane: f, c, b', discriminant) runs until the lane meets a slot whose
+       * discriminant is >= +0; only then do the lanes that found one run the HEAVY part (sqrt, divide)
+       * together.  Testing slot after slot in lockstep would execute ~50 sqrt/div instructions per slot with
+       * one lane in eight active.  Slots are still visited in order, so `t <= t_found` ties resolve alike. */
+#if PT_PACKET_DEFER
+      /* pass 1, lockstep over the slots: only the discriminant's sign; pass 2: the roots of the candidates, in slot
+       * order.  The discriminant does not depend on the closest hit so far, so deferring the roots changes nothing. */
+      for (int base = 0; base < leaf_n; base += 32) {
+        const int m = (leaf_n - base) < 32 ? (leaf_n - base) : 32;
+        uint32_t cand = 0;
+        for (int k = 0; k < m; ++k) {
+          if (COUNT && PT_DIAG == 3 && !ORIGIN_ZERO) {
+            c_nodes++;
+            PT_DIAG_WAVE_SLOTS(c_floor);
+          }
+          const double* s = sv.sph + (size_t)(leaf_first + base + k) * 4;
+          const double fx = ORIGIN_ZERO ? s[0] : s[0] - o.x, fy = ORIGIN_ZERO ? s[1] : s[1] - o.y,
+                       fz = ORIGIN_ZERO ? s[2] : s[2] - o.z;
+          const double bp_over_a = pt_fma(fx, d.x, pt_fma(fy, d.y, fz * d.z)) * one_over_a;
+          const double wx = pt_fma(d.x, bp_over_a, -fx);
+          const double wy = pt_fma(d.y, bp_over_a, -fy);
+          const double wz = pt_fma(d.z, bp_over_a, -fz);
+          const double disc = (s[3] * s[3]) - pt_fma(wx, wx, pt_fma(wy, wy, wz * wz));
+          if ((disc == disc) && !pt_signbit(disc)) cand |= 1u << k;
+        }
+        while (cand != 0) {
+          if (COUNT && PT_DIAG == 4 && !ORIGIN_ZERO) {
+            c_nodes++;
+            PT_DIAG_WAVE_SLOTS(c_floor);
+          }
+          const int k = __ffs((int)cand) - 1;
+          cand &= cand - 1u;
+          const double* s = sv.sph + (size_t)(leaf_first + base + k) * 4;
+          const double fx = ORIGIN_ZERO ? s[0] : s[0] - o.x, fy = ORIGIN_ZERO ? s[1] : s[1] - o.y,
+                       fz = ORIGIN_ZERO ? s[2] : s[2] - o.z;
+          const double r2 = s[3] * s[3];
+          const double c = pt_fma(fx, fx, pt_fma(fy, fy, fz * fz)) - r2;
+          const double bp = pt_fma(fx, d.x, pt_fma(fy, d.y, fz * d.z));
+          const double bp_over_a = bp * one_over_a;
+          const double wx = pt_fma(d.x, bp_over_a, -fx);
+          const double wy = pt_fma(d.y, bp_over_a, -fy);
+          const double wz = pt_fma(d.z, bp_over_a, -fz);
+          const double disc = r2 - pt_fma(wx, wx, pt_fma(wy, wy, wz * wz));
+          const double q_rhs = pt_sqrt(qa * disc);
+          const double qq = pt_signbit(bp) ? (bp - q_rhs) : (bp + q_rhs);
+          const double t = pt_signbit(c) ? (qq * one_over_a) : (c / qq);
+          if (!(t < t_min) && t <= r.t) {
+            r.t = t;
+            r.slot = leaf_first + base + k;
+          }
+        }
+      }
+#else
+      int k = 0;
+      while (k < leaf_n) {
+        double c = 0.0, bp = 0.0, disc = 0.0;
+        bool found = false;
+        while (k < leaf_n && !found) {
+          if (COUNT && PT_DIAG == 3 && !ORIGIN_ZERO) {
+            c_nodes++;
+            PT_DIAG_WAVE_SLOTS(c_floor);
+          }
+          const double* s = sv.sph + (size_t)(leaf_first + k) * 4;
+          const double fx = ORIGIN_ZERO ? s[0] : s[0] - o.x, fy = ORIGIN_ZERO ? s[1] : s[1] - o.y,
+                       fz = ORIGIN_ZERO ? s[2] : s[2] - o.z; /* f = center - origin */
+          const double r2 = s[3] * s[3];
+          c = pt_fma(fx, fx, pt_fma(fy, fy, fz * fz)) - r2;
+          bp = pt_fma(fx, d.x, pt_fma(fy, d.y, fz * d.z));
+          const double bp_over_a = bp * one_over_a;
+          const double wx = pt_fma(d.x, bp_over_a, -fx);
+          const double wy = pt_fma(d.y, bp_over_a, -fy);
+          const double wz = pt_fma(d.z, bp_over_a, -fz);
+          const double wq = pt_fma(wx, wx, pt_fma(wy, wy, wz * wz));
+          disc = r2 - wq;
+          /* lanes whose discriminant has its sign bit set (or is NaN) end up NaN (lib.rs:162-166) */
+          found = (disc == disc) && !pt_signbit(disc);
+          ++k;
+        }
+        if (COUNT && PT_DIAG == 4 && !ORIGIN_ZERO) {
+          if (found) c_nodes++;
+          if (__ballot(found)) PT_DIAG_WAVE_SLOTS(c_floor);
+        }
+        if (found) {
+          const double q_rhs = pt_sqrt(qa * disc);
+          const double qq = pt_signbit(bp) ? (bp - q_rhs) : (bp + q_rhs);
+          const double t = pt_signbit(c) ? (qq * one_over_a) : (c / qq);
+          /* not (t < t_min), not (t > t_max), then `t <= t_found` (last index wins ties, lib.rs:169-177) */
+          if (!(t < t_min) && t <= r.t) {
+            r.t = t;
+            r.slot = leaf_first + k - 1;
+          }
+        }
+      }
+#endif
+    } else {
+      /* Array_leaf.intersect, shape_tree.ml:299-311: shrinking t_max, later element wins ties */
+      for (int k = 0; k < leaf_n; ++k) {
+        const int slot = leaf_first + k;
+        if (sv.kind[slot] == PT_SLOT_SPHERE) {
+          const double* s = sv.sph + (size_t)slot * 4;
+          double t;
+          if (pt_sphere_intersect_scalar(v3(s[0], s[1], s[2]), s[3], o, d, t_min, r.t, &t)) {
+            r.t = t;
+            r.slot = slot;
+          }
+        } else {
+          const double* tv = sv.tri + (size_t)slot * 10;
+          double t, u, v;
+          if (pt_triangle_intersect(pt_load_v3(tv), pt_load_v3(tv + 3), pt_load_v3(tv + 6), o, d, t_min, r.t, &t, &u,
+                                    &v)) {
+            r.t = t;
+            r.u = u;
+            r.v = v;
+            r.slot = slot;
+          }
+        }
+      }
+    }
+    leaf_n = 0;
+  }
+};
+
+/* Scene.intersect for ONE ray held by this lane, start to finish.
+ * "while-while" traversal: every lane walks nodes until it reaches a leaf (or runs out of nodes); only then do the
+ * lanes that hold a leaf test its packet TOGETHER.  Interleaving the two, as the recursive reference does, would
+ * run the packet loop for one or two lanes at a time.  The order of node tests and packet tests of each individual
+ * ray is unchanged. */
 template <int MODE, bool COUNT, bool ORIGIN_ZERO, typename StackT, bool SWZ = false>
 __device__ __forceinline__ PtTraceResult pt_trace_ray(const PtSceneDev& sc, const PtSceneView& sv, StackT* stack,
                                                       V3 o, V3 d, unsigned long long& c_nodes,
                                                       unsigned long long& c_prims, unsigned long long& c_floor) {
-  const V3 inv = v3(1.0 / d.x, 1.0 / d.y, 1.0 / d.z); /* Ray.create, ray.ml:7-10 */
-  /* dirs, shape_tree.ml:201 */
-  const uint32_t dirs = (d.x >= 0.0 ? 1u : 0u) | (d.y >= 0.0 ? 2u : 0u) | (d.z >= 0.0 ? 4u : 0u);
-  const bool exact_slab = !(pt_isfinite(inv.x) && pt_isfinite(inv.y) && pt_isfinite(inv.z));
-  /* byte offsets of the (near, far) pair of each axis inside a swizzled LDS node */
-  uint3 swz_off;
-  swz_off.x = 0u + (inv.x < 0.0 ? 8u : 0u);
-  swz_off.y = 24u + (inv.y < 0.0 ? 8u : 0u);
-  swz_off.z = 48u + (inv.z < 0.0 ? 8u : 0u);
-  const double t_min = 0.0;
-  PtTraceResult r;
-  r.t = PT_MAX_FINITE;
-  r.slot = -1;
-  r.u = 0.0;
-  r.v = 0.0;
-
-  /* ganesha Floor.intersect (main.ml:247-256): f1 then f2, the first hit clips t_max for the tree */
-  if (MODE == PT_MODE_ARRAY && sc.n_floor > 0) {
-    for (int f = 0; f < sc.n_floor; ++f) {
-      const double* tv = sv.tri + (size_t)(sc.n_slots + f) * 10;
-      double t, u, v;
-      if (COUNT) c_floor++;
-      if (pt_triangle_intersect(pt_load_v3(tv), pt_load_v3(tv + 3), pt_load_v3(tv + 6), o, d, 0.0, PT_MAX_FINITE, &t,
-                                &u, &v)) {
-        r.t = t;
-        r.u = u;
-        r.v = v;
-        r.slot = sc.n_slots + f;
-        break;
-      }
-    }
-  }
-
-  /* packet constants of spheres_intersect_aux (lib.rs:115-117): a is the UNFUSED scalar dot */
-  double qa = 0.0, one_over_a = 0.0;
-  if (MODE == PT_MODE_SIMD) {
-    qa = d.x * d.x + d.y * d.y + d.z * d.z;
-    one_over_a = 1.0 / qa;
-  }
-  if (sc.n_nodes <= 0) return r;
-
-  /* "while-while" traversal: every lane walks nodes until it reaches a leaf (or runs out of nodes); only
-   * then do the lanes that hold a leaf test its packet TOGETHER.  Interleaving the two, as the recursive
-   * reference does, would run the packet loop for one or two lanes at a time.  The order of node tests and
-   * packet tests of each individual ray is unchanged. */
-  int sp = 0;
-  uint32_t node = 0;
-  bool walking = true;
-  int leaf_first = 0, leaf_n = 0;
-  while (walking || leaf_n > 0) {
+  PtTraverser<MODE, COUNT, ORIGIN_ZERO, StackT, SWZ> tr;
+  tr.begin(sc, sv, o, d, c_floor);
+  while (tr.walking || tr.leaf_n > 0) {
     for (;;) {
       /* keep walking while enough lanes still want a node step; once fewer than PT_WALK_MIN do and some lane
        * already holds a leaf, intersect the pending packets first (the stragglers resume afterwards) */
-      const bool want = walking && leaf_n == 0;
+      const bool want = tr.wants_node();
       const unsigned long long wm = __ballot(want);
       if (wm == 0) break;
-      if ((int)__popcll(wm) < PT_WALK_MIN && __ballot(leaf_n > 0) != 0) break;
+      if ((int)__popcll(wm) < PT_WALK_MIN && __ballot(tr.leaf_n > 0) != 0) break;
+      if (COUNT && PT_DIAG == 1 && !ORIGIN_ZERO) PT_DIAG_WAVE_SLOTS(c_floor);
       if (!want) continue;
-      if (COUNT) c_nodes++;
-      bool descend = false;
-      bool hit;
-      uint32_t na, nb, n_real;
-      if (SWZ) {
-        const unsigned char* nbase = sv.swz_nodes + (size_t)node * PT_SWZ_NODE_BYTES;
-        const uint2 links = *(const uint2*)(nbase + 72);
-        na = links.x;
-        nb = links.y;
-        n_real = *(const uint32_t*)(nbase + 80);
-        if (exact_slab) {
-          const double* bx = (const double*)nbase;
-          const double box6[6] = {bx[0], bx[3], bx[6], bx[1], bx[4], bx[7]};
-          hit = pt_slab_hit_exact(box6, o, inv, t_min, r.t);
-        } else {
-          /* (near, far) per axis, selected by the sign of the direction component through the load address */
-          /* 8-byte aligned pairs (ds_read2_b64): the +8 variants are not 16-byte aligned */
-          const double* px = (const double*)(nbase + swz_off.x);
-          const double* py = (const double*)(nbase + swz_off.y);
-          const double* pz = (const double*)(nbase + swz_off.z);
-          const double tnx = (ORIGIN_ZERO ? px[0] : px[0] - o.x) * inv.x, tfx = (ORIGIN_ZERO ? px[1] : px[1] - o.x) * inv.x;
-          const double tny = (ORIGIN_ZERO ? py[0] : py[0] - o.y) * inv.y, tfy = (ORIGIN_ZERO ? py[1] : py[1] - o.y) * inv.y;
-          const double tnz = (ORIGIN_ZERO ? pz[0] : pz[0] - o.z) * inv.z, tfz = (ORIGIN_ZERO ? pz[1] : pz[1] - o.z) * inv.z;
-          const double a = __builtin_fmax(tnx, __builtin_fmax(tny, tnz));
-          const double b = __builtin_fmin(tfx, __builtin_fmin(tfy, tfz));
-          hit = __builtin_fmax(t_min, a) <= __builtin_fmin(r.t, b);
-        }
-      } else {
-        const PtNode* np = sv.nodes + node;
-        hit = exact_slab ? pt_slab_hit_exact(np->mn, o, inv, t_min, r.t) : pt_slab_hit_fast<ORIGIN_ZERO>(np->mn, o, inv, t_min, r.t);
-        na = np->a;
-        nb = np->b;
-        n_real = np->pad[0];
-      }
-      if (hit) {
-        const uint32_t axis = nb >> 30;
-        if (axis == PT_NODE_LEAF_AXIS) {
-          leaf_first = (int)na;
-          leaf_n = (int)n_real; /* real slots; the NaN padding (main.ml:185) can never be selected */
-          if (COUNT) c_prims += (unsigned long long)(nb & 0x3fffffffu); /* Leaf.length incl. padding */
-        } else {
-          /* Branch: near child first (shape_tree.ml:209), far child deferred */
-          const uint32_t lhs = na, rhs = nb & 0x3fffffffu;
-          const bool lhs_first = (dirs >> axis) & 1u;
-          PT_STACK_PUSH(stack, sp, lhs_first ? rhs : lhs);
-          ++sp;
-          node = lhs_first ? lhs : rhs;
-          descend = true;
-        }
-      }
-      if (!descend) {
-        /* the popped node's bbox is tested on the NEXT visit, i.e. after this leaf's packet has been
-         * intersected and r.t shrunk -- the t_max the reference passes to the far child */
-        if (sp == 0) walking = false;
-        else {
-          --sp;
-          node = PT_STACK_POP(stack, sp);
-        }
-      }
+      tr.node_step(sv, stack, c_nodes, c_prims);
     }
-    if (leaf_n > 0) {
-      if (MODE == PT_MODE_SIMD) {
-        /* spheres_intersect_aux, lib.rs:102-178, one packet lane per step, split in two so the wave stays
-         * dense: SCAN (cheap, every lane: f, c, b', discriminant) runs until the lane meets a slot whose
-         * discriminant is >= +0; only then do the lanes that found one run the HEAVY part (sqrt, divide)
-         * together.  Testing slot after slot in lockstep would execute ~50 sqrt/div instructions per slot with
-         * one lane in eight active.  Slots are still visited in order, so `t <= t_found` ties resolve alike. */
-        int k = 0;
-        while (k < leaf_n) {
-          double c = 0.0, bp = 0.0, disc = 0.0;
-          bool found = false;
-          while (k < leaf_n && !found) {
-            const double* s = sv.sph + (size_t)(leaf_first + k) * 4;
-            const double fx = ORIGIN_ZERO ? s[0] : s[0] - o.x, fy = ORIGIN_ZERO ? s[1] : s[1] - o.y,
-                         fz = ORIGIN_ZERO ? s[2] : s[2] - o.z; /* f = center - origin */
-            const double r2 = s[3] * s[3];
-            c = pt_fma(fx, fx, pt_fma(fy, fy, fz * fz)) - r2;
-            bp = pt_fma(fx, d.x, pt_fma(fy, d.y, fz * d.z));
-            const double bp_over_a = bp * one_over_a;
-            const double wx = pt_fma(d.x, bp_over_a, -fx);
-            const double wy = pt_fma(d.y, bp_over_a, -fy);
-            const double wz = pt_fma(d.z, bp_over_a, -fz);
-            const double wq = pt_fma(wx, wx, pt_fma(wy, wy, wz * wz));
-            disc = r2 - wq;
-            /* lanes whose discriminant has its sign bit set (or is NaN) end up NaN (lib.rs:162-166) */
-            found = (disc == disc) && !pt_signbit(disc);
-            ++k;
-          }
-          if (found) {
-            const double q_rhs = pt_sqrt(qa * disc);
-            const double qq = pt_signbit(bp) ? (bp - q_rhs) : (bp + q_rhs);
-            const double t = pt_signbit(c) ? (qq * one_over_a) : (c / qq);
-            /* not (t < t_min), not (t > t_max), then `t <= t_found` (last index wins ties, lib.rs:169-177) */
-            if (!(t < t_min) && t <= r.t) {
-              r.t = t;
-              r.slot = leaf_first + k - 1;
-            }
-          }
-        }
-      } else {
-        /* Array_leaf.intersect, shape_tree.ml:299-311: shrinking t_max, later element wins ties */
-        for (int k = 0; k < leaf_n; ++k) {
-          const int slot = leaf_first + k;
-          if (sv.kind[slot] == PT_SLOT_SPHERE) {
-            const double* s = sv.sph + (size_t)slot * 4;
-            double t;
-            if (pt_sphere_intersect_scalar(v3(s[0], s[1], s[2]), s[3], o, d, t_min, r.t, &t)) {
-              r.t = t;
-              r.slot = slot;
-            }
-          } else {
-            const double* tv = sv.tri + (size_t)slot * 10;
-            double t, u, v;
-            if (pt_triangle_intersect(pt_load_v3(tv), pt_load_v3(tv + 3), pt_load_v3(tv + 6), o, d, t_min, r.t, &t, &u,
-                                      &v)) {
-              r.t = t;
-              r.u = u;
-              r.v = v;
-              r.slot = slot;
-            }
-          }
-        }
-      }
-      leaf_n = 0;
-    }
+    if (tr.leaf_n > 0) tr.packet(sv, c_nodes, c_floor);
   }
-  return r;
+  return tr.r;
 }
 
-/* The traverse + intersect stage.  PRIMARY: bounce 0, rays come from the sampler + camera, not from a queue.
- * LDS_SCENE: the whole tree and every leaf packet are first copied into LDS (small scenes: Shirley is
- * 22 KB of nodes + 22 KB of packets), so node / packet reads are ds_read_b128 instead of L1 traffic.
- * LDS layout: [traversal stacks: waves x depth x 64 u32][nodes][sphere slots][triangle slots][slot kinds] */
-#ifndef PT_TRACE_GLOBAL_WAVES
-#define PT_TRACE_GLOBAL_WAVES 4
-#endif
-template <int MODE, bool COUNT, bool PRIMARY, bool LDS_SCENE>
-/* Simd_leaf + LDS scene fits 64 VGPRs without spilling: ask for 2 x 1024-thread workgroups per CU.  The Array_leaf
- * variants (triangle / scalar-sphere code) need ~100 VGPRs: forcing 64 would spill to scratch (1.5 GB of HBM
- * writes per launch on cornell). */
-__global__ __launch_bounds__(LDS_SCENE ? 1024 : 512, (LDS_SCENE && MODE == PT_MODE_SIMD) ? 8 : PT_TRACE_GLOBAL_WAVES) void k_trace(PtSceneDev sc, PtQueue q, PtHits hits, int stack_depth,
-                                               PtCounters* counters, PtGenParams g, const double* __restrict__ alpha,
-                                               uint32_t n_primary) {
-  extern __shared__ __attribute__((aligned(64))) unsigned char lds_raw[];
-  const int lane = pt_lane();
-  const int wave_in_block = (int)(threadIdx.x >> 6);
+/* Where this workgroup traverses from.  LDS_SCENE: the whole tree and every leaf packet are first copied into LDS
+ * behind the traversal stacks (nodes expanded to the swizzled image on the way); ends with a __syncthreads(). */
+template <int MODE, bool LDS_SCENE, typename StackT>
+__device__ __forceinline__ PtSceneView pt_scene_view(const PtSceneDev& sc, unsigned char* lds_raw, int stack_depth) {
   const uint32_t waves_per_block = blockDim.x >> 6;
-  /* LDS-resident scenes have < 65536 nodes: 16-bit stack entries halve the stack footprint */
-  typedef typename std::conditional<LDS_SCENE, uint16_t, uint32_t>::type StackT;
-  StackT* stack = (StackT*)lds_raw + (size_t)wave_in_block * stack_depth * PT_WAVE + lane;
   PtSceneView sv;
   sv.nodes = sc.nodes;
   sv.swz_nodes = nullptr;
@@ -527,6 +615,31 @@ __global__ __launch_bounds__(LDS_SCENE ? 1024 : 512, (LDS_SCENE && MODE == PT_MO
     sv.tri = l_tri;
     sv.kind = l_kind;
   }
+  return sv;
+}
+
+/* The traverse + intersect stage.  PRIMARY: bounce 0, rays come from the sampler + camera, not from a queue.
+ * LDS_SCENE: the whole tree and every leaf packet are first copied into LDS (small scenes: Shirley is
+ * 22 KB of nodes + 22 KB of packets), so node / packet reads are ds_read_b128 instead of L1 traffic.
+ * LDS layout: [traversal stacks: waves x depth x 64 u32][nodes][sphere slots][triangle slots][slot kinds] */
+#ifndef PT_TRACE_GLOBAL_WAVES
+#define PT_TRACE_GLOBAL_WAVES 4
+#endif
+template <int MODE, bool COUNT, bool PRIMARY, bool LDS_SCENE>
+/* Simd_leaf + LDS scene fits 64 VGPRs without spilling: ask for 2 x 1024-thread workgroups per CU.  The Array_leaf
+ * variants (triangle / scalar-sphere code) need ~100 VGPRs: forcing 64 would spill to scratch (1.5 GB of HBM
+ * writes per launch on cornell). */
+__global__ __launch_bounds__(LDS_SCENE ? 1024 : 512, (LDS_SCENE && MODE == PT_MODE_SIMD) ? 8 : PT_TRACE_GLOBAL_WAVES) void k_trace(PtSceneDev sc, PtQueue q, PtHits hits, int stack_depth,
+                                               PtCounters* counters, PtGenParams g, const double* __restrict__ alpha,
+                                               uint32_t n_primary) {
+  extern __shared__ __attribute__((aligned(64))) unsigned char lds_raw[];
+  const int lane = pt_lane();
+  const int wave_in_block = (int)(threadIdx.x >> 6);
+  const uint32_t waves_per_block = blockDim.x >> 6;
+  /* LDS-resident scenes have < 65536 nodes: 16-bit stack entries halve the stack footprint */
+  typedef typename std::conditional<LDS_SCENE, uint16_t, uint32_t>::type StackT;
+  StackT* stack = (StackT*)lds_raw + (size_t)wave_in_block * stack_depth * PT_WAVE + lane;
+  const PtSceneView sv = pt_scene_view<MODE, LDS_SCENE, StackT>(sc, lds_raw, stack_depth);
   const uint32_t n = PRIMARY ? n_primary : *q.count;
   const uint32_t gwave = blockIdx.x * waves_per_block + wave_in_block;
   const uint32_t nwaves = gridDim.x * waves_per_block;
@@ -546,7 +659,17 @@ __global__ __launch_bounds__(LDS_SCENE ? 1024 : 512, (LDS_SCENE && MODE == PT_MO
       d = v3(q.dx[i], q.dy[i], q.dz[i]);
     }
     if (COUNT) c_seg++;
+    const unsigned long long diag_n0 = c_nodes;
     const PtTraceResult r = pt_trace_ray<MODE, COUNT, PRIMARY, StackT, LDS_SCENE>(sc, sv, stack, o, d, c_nodes, c_prims, c_floor);
+    if (COUNT && PT_DIAG == 2 && !PRIMARY) {
+      unsigned long long m = c_nodes - diag_n0;
+      for (int off = 32; off > 0; off >>= 1) {
+        const unsigned long long other = __shfl_xor(m, off);
+        m = other > m ? other : m;
+      }
+      PT_DIAG_WAVE_SLOTS(c_floor);
+      if (lane == 0) c_floor += m * 64 - 64;
+    }
     hits.t[i] = r.t;
     hits.slot[i] = r.slot;
     if (MODE == PT_MODE_ARRAY && sc.has_triangles) {
