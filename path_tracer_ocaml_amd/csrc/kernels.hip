@@ -275,7 +275,8 @@ struct PtTraceResult {
 
 /* One ray's traversal state.  begin() = Ray.create + the per-ray constants; node_step() = one visit of
  * Tree.intersect's recursion (shape_tree.ml:203-221); packet() = Leaf.intersect on the leaf the lane holds.
- * pt_trace_ray drives it (one ray per lane, start to finish). */
+ * Two drivers use it: pt_trace_ray (one ray per lane, start to finish) and k_trace_stream (lanes are handed a new
+ * ray as soon as enough of the wave has finished). */
 template <int MODE, bool COUNT, bool ORIGIN_ZERO, typename StackT, bool SWZ>
 struct PtTraverser {
   V3 o, d, inv;
@@ -289,6 +290,11 @@ struct PtTraverser {
   bool walking;
   int leaf_first, leaf_n;
   __device__ __forceinline__ bool wants_node() const { return walking && leaf_n == 0; }
+  __device__ __forceinline__ bool idle() const { return !walking && leaf_n == 0; }
+  __device__ __forceinline__ void park() {
+    walking = false;
+    leaf_n = 0;
+  }
 
   __device__ __forceinline__ void begin(const PtSceneDev& sc, const PtSceneView& sv, V3 o_, V3 d_,
                                         unsigned long long& c_floor) {
@@ -505,6 +511,10 @@ struct PtTraverser {
     } else {
       /* Array_leaf.intersect, shape_tree.ml:299-311: shrinking t_max, later element wins ties */
       for (int k = 0; k < leaf_n; ++k) {
+        if (COUNT && PT_DIAG == 3 && !ORIGIN_ZERO) {
+          c_nodes++;
+          PT_DIAG_WAVE_SLOTS(c_floor);
+        }
         const int slot = leaf_first + k;
         if (sv.kind[slot] == PT_SLOT_SPHERE) {
           const double* s = sv.sph + (size_t)slot * 4;
@@ -676,6 +686,101 @@ __global__ __launch_bounds__(LDS_SCENE ? 1024 : 512, (LDS_SCENE && MODE == PT_MO
       hits.u[i] = r.u;
       hits.v[i] = r.v;
     }
+  }
+  if (COUNT) {
+    c_nodes = pt_wave_sum(c_nodes);
+    c_prims = pt_wave_sum(c_prims);
+    c_floor = pt_wave_sum(c_floor);
+    c_seg = pt_wave_sum(c_seg);
+    if (lane == 0) {
+      atomicAdd(&counters->nodes, c_nodes);
+      atomicAdd(&counters->prims, c_prims);
+      atomicAdd(&counters->floor, c_floor);
+      atomicAdd(&counters->segments, c_seg);
+    }
+  }
+}
+
+/* The same stage for queued (bounce >= 1) rays as a STREAM: a lane whose ray has finished does not wait for the
+ * slowest ray of its group of 64 -- once PT_REFILL_MIN lanes are idle they hand in their results and take the next
+ * rays of the wave's share of the queue.  On a large mesh most bounce rays leave for the sky after 1-3 node tests
+ * while a few walk 100+ nodes: with fixed groups of 64 the node walk ran at 23 % lane utilisation (ganesha-like,
+ * tools/diag_utilisation.sh), nearly all of it lanes waiting for the group's longest ray.
+ * The wave owns queue chunks gwave, gwave + nwaves, ... of 64 rays and numbers their entries 0, 1, 2, ... in that
+ * order ("positions"); idle lanes take consecutive positions, so refill reads stay coalesced and no atomics are
+ * needed.  Every ray still runs exactly pt_trace_ray's sequence of node and packet tests. */
+#ifndef PT_REFILL_MIN
+#define PT_REFILL_MIN 24
+#endif
+#ifndef PT_STREAM_WALK_MIN
+#define PT_STREAM_WALK_MIN 16
+#endif
+template <int MODE, bool COUNT, bool LDS_SCENE>
+__global__ __launch_bounds__(LDS_SCENE ? 1024 : 512, PT_TRACE_GLOBAL_WAVES) void k_trace_stream(
+    PtSceneDev sc, PtQueue q, PtHits hits, int stack_depth, PtCounters* counters) {
+  extern __shared__ __attribute__((aligned(64))) unsigned char lds_raw[];
+  const int lane = pt_lane();
+  const int wave_in_block = (int)(threadIdx.x >> 6);
+  const uint32_t waves_per_block = blockDim.x >> 6;
+  typedef typename std::conditional<LDS_SCENE, uint16_t, uint32_t>::type StackT;
+  StackT* stack = (StackT*)lds_raw + (size_t)wave_in_block * stack_depth * PT_WAVE + lane;
+  const PtSceneView sv = pt_scene_view<MODE, LDS_SCENE, StackT>(sc, lds_raw, stack_depth);
+  const uint32_t n = *q.count;
+  const uint32_t gwave = blockIdx.x * waves_per_block + wave_in_block;
+  const uint32_t nwaves = gridDim.x * waves_per_block;
+  const uint32_t total_chunks = (n + PT_WAVE - 1) / PT_WAVE;
+  const uint32_t my_positions = gwave < total_chunks ? ((total_chunks - gwave + nwaves - 1) / nwaves) * PT_WAVE : 0u;
+  unsigned long long c_nodes = 0, c_prims = 0, c_floor = 0, c_seg = 0;
+
+  PtTraverser<MODE, COUNT, false, StackT, LDS_SCENE> tr;
+  tr.park();
+  tr.r.t = 0.0;
+  tr.r.u = 0.0;
+  tr.r.v = 0.0;
+  tr.r.slot = -1;
+  uint32_t ray = 0xffffffffu; /* queue index of the ray this lane holds */
+  uint32_t pos = 0;           /* wave-uniform: next position nobody holds yet */
+  for (;;) {
+    const bool idle = tr.idle();
+    const unsigned long long im = __ballot(idle);
+    const bool more = pos < my_positions;
+    if (im == ~0ull || (more && (int)__popcll(im) >= PT_REFILL_MIN)) {
+      /* hand in the finished rays, take the next positions */
+      if (idle && ray != 0xffffffffu) {
+        hits.t[ray] = tr.r.t;
+        hits.slot[ray] = tr.r.slot;
+        if (MODE == PT_MODE_ARRAY && sc.has_triangles) {
+          hits.u[ray] = tr.r.u;
+          hits.v[ray] = tr.r.v;
+        }
+        ray = 0xffffffffu;
+      }
+      if (!more) break; /* every lane idle and nothing left */
+      if (idle) {
+        const uint32_t p = pos + (uint32_t)__popcll(im & ((1ull << lane) - 1ull));
+        const uint32_t i = (gwave + (p >> 6) * nwaves) * PT_WAVE + (p & 63u);
+        if (p < my_positions && i < n) {
+          ray = i;
+          if (COUNT) c_seg++;
+          tr.begin(sc, sv, v3(q.ox[i], q.oy[i], q.oz[i]), v3(q.dx[i], q.dy[i], q.dz[i]), c_floor);
+        }
+      }
+      pos += (uint32_t)__popcll(im);
+      continue;
+    }
+    for (;;) {
+      const bool want = tr.wants_node();
+      const unsigned long long wm = __ballot(want);
+      if (wm == 0) break;
+      if ((int)__popcll(wm) < PT_STREAM_WALK_MIN && __ballot(tr.leaf_n > 0) != 0) break;
+      if (more && (int)__popcll(__ballot(tr.idle())) >= PT_REFILL_MIN) break;
+      if (COUNT && PT_DIAG == 1) PT_DIAG_WAVE_SLOTS(c_floor);
+      if (!want) continue;
+      tr.node_step(sv, stack, c_nodes, c_prims);
+    }
+    /* also when the walk stopped for a refill: the lanes that hold a leaf test it now and walk on together with the
+     * newcomers (making them wait for the newcomers' first leaf cost more walk utilisation than it saved here) */
+    if (tr.leaf_n > 0) tr.packet(sv, c_nodes, c_floor);
   }
   if (COUNT) {
     c_nodes = pt_wave_sum(c_nodes);
