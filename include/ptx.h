@@ -120,7 +120,7 @@ typedef struct ptx_scene_desc {
   int32_t leaf_kind;
   int32_t length_cutoff; /* 16 for SIMD (lib.rs:13), 4 / 2 / 8 for the array leaves */
   int32_t num_bins;      /* 0 -> 32 */
-  int32_t reserved;      /* BVH builder: 0 auto (GPU for >= 8192 primitives, else host), 1 host, 2 GPU -- same tree */
+  int32_t reserved;      /* BVH builder: 0 auto (GPU for >= 4096 primitives, else host), 1 host, 2 GPU -- same tree */
 } ptx_scene_desc;
 
 /* ---- render parameters: Render_command.Args.t (render_command.ml:7-14) ---- */

@@ -299,12 +299,16 @@ def _force_builder(P, desc_ptr, which):
     return d
 
 
-@pytest.mark.parametrize("name", ["shirley", "shirley_no_simd", "cornell", "ganesha_20k", "ganesha_150k"])
+@pytest.mark.parametrize("name", ["shirley", "shirley_no_simd", "cornell", "ganesha_300", "ganesha_3k", "ganesha_9k",
+                                  "ganesha_20k", "ganesha_60k", "ganesha_150k"])
 def test_gpu_bvh_build_equals_oracle_tree(P, oracle, name):
     """Shape_tree.create on the GPU (level-synchronous binned SAH + exact Hoare-partition emulation): the same
     tree, boxes bit for bit, and the same element order inside every leaf as the oracle's recursive builder."""
     od = {"shirley": lambda: oracle.desc_shirley(600, 300), "shirley_no_simd": lambda: oracle.desc_shirley(600, 300, no_simd=True),
           "cornell": lambda: oracle.desc_cornell(256, 256), "ganesha_20k": lambda: oracle.desc_ganesha_like(192, 108, 20000),
+          # sizes on both sides of the builder's segment classes (one wave <= 64 < one workgroup < 8192 <= tiled)
+          "ganesha_300": lambda: oracle.desc_ganesha_like(192, 108, 300), "ganesha_3k": lambda: oracle.desc_ganesha_like(192, 108, 3000),
+          "ganesha_9k": lambda: oracle.desc_ganesha_like(192, 108, 9000), "ganesha_60k": lambda: oracle.desc_ganesha_like(192, 108, 60000),
           "ganesha_150k": lambda: oracle.desc_ganesha_like(1920, 1080, 150000)}[name]()
     ob, oi, oo = oracle.Scene(od.ptr, od).tree()
     g = P.Scene(_force_builder(P, od.ptr, 2), 0, keepalive=od)

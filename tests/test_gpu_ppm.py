@@ -38,6 +38,23 @@ def test_ppm_cornell_point_light(P, oracle):
     assert st["photons_stored"] > 50000 and st["neighbors"] > 1_000_000
 
 
+def test_ppm_host_side_list_and_tree(P, oracle, monkeypatch):
+    """PTX_PPM_HOST_LIST=1: the photon list and the photon tree are made on the host (the path small maps take)."""
+    from path_tracer_ocaml_amd import abi
+    monkeypatch.setenv("PTX_PPM_HOST_LIST", "1")
+    w = h = 96
+    d = oracle.desc_cornell(w, h, 0.0)
+    _check(P, oracle, d, oracle.lights_cornell(w, h), abi.ppm_params(w, h, iterations=2, photon_count=12000))
+
+
+def test_ppm_small_map_below_gpu_build_threshold(P, oracle):
+    from path_tracer_ocaml_amd import abi
+    w = h = 64
+    d = oracle.desc_cornell(w, h, 0.0)
+    _, st = _check(P, oracle, d, oracle.lights_cornell(w, h), abi.ppm_params(w, h, iterations=2, photon_count=2000))
+    assert st["photons_stored"] < 2 * 8192
+
+
 def test_ppm_ganesha_like_two_spot_lights(P, oracle):
     from path_tracer_ocaml_amd import abi
     w, h = 160, 90
