@@ -1011,6 +1011,7 @@ __device__ __forceinline__ uint32_t pt_block_append(uint32_t* counter, bool keep
  * octant of the new ray): inside the workgroup's slice of the output queue, rays of one octant are contiguous,
  * so the waves of the next trace launch walk the tree in the same child order.  One atomic per iteration.
  * lds: PT_APPEND_BINS * (blockDim/64) + 1 words (<= 65). */
+static_assert(PT_APPEND_BINS == 1 || PT_APPEND_BINS == 8, "the bin key is the direction octant (0..7)");
 __device__ __forceinline__ uint32_t pt_block_append_binned(uint32_t* counter, bool keep, int key, uint32_t* lds) {
   const int lane = pt_lane();
   const int wave = (int)(threadIdx.x >> 6), nw = (int)(blockDim.x >> 6);
@@ -1081,8 +1082,14 @@ __device__ __forceinline__ uint32_t pt_block_sort_by_category(int key, uint32_t*
   return (uint32_t)perm[threadIdx.x];
 }
 
+#ifndef PT_SHADE_BLOCK
+#define PT_SHADE_BLOCK 512 /* <= 512: the category / bin tables are scanned by one wave (<= 64 entries) */
+#endif
+#ifndef PT_SHADE_WAVES
+#define PT_SHADE_WAVES 4
+#endif
 template <bool EMIT, bool PRIMARY>
-__global__ __launch_bounds__(512, 4) void k_shade(PtSceneDev sc, PtQueue q, PtHits hits, PtQueue out, PtContrib contrib,
+__global__ __launch_bounds__(PT_SHADE_BLOCK, PT_SHADE_WAVES) void k_shade(PtSceneDev sc, PtQueue q, PtHits hits, PtQueue out, PtContrib contrib,
                                                 const double* __restrict__ alpha, int bounce, int last_bounce,
                                                 PtGenParams g, uint32_t n_primary) {
 #if PT_APPEND_BINS > 1
@@ -1091,7 +1098,7 @@ __global__ __launch_bounds__(512, 4) void k_shade(PtSceneDev sc, PtQueue q, PtHi
   __shared__ uint32_t lds_append[17];
 #endif
   __shared__ uint32_t lds_cnt[PT_N_CAT * 8];
-  __shared__ uint16_t lds_perm[512];
+  __shared__ uint16_t lds_perm[PT_SHADE_BLOCK];
   const uint32_t n = PRIMARY ? n_primary : *q.count;
   const double pi = 3.14159265358979323846;
 
