@@ -14,14 +14,19 @@ src, tag, workload = sys.argv[1], sys.argv[2], sys.argv[3]
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 dst = os.path.join(root, "profiles")
 os.makedirs(dst, exist_ok=True)
-stats = glob.glob(os.path.join(src, "ktrace", "*", "*kernel_stats.csv"))[0]
+def newest(pattern):
+    """gpurun merges every call's files into the same local directory: take the latest run's file"""
+    return max(glob.glob(pattern), key=os.path.getmtime)
+
+
+stats = newest(os.path.join(src, "ktrace", "*", "*kernel_stats.csv"))
 shutil.copy(stats, os.path.join(dst, f"{tag}_kernel_stats.csv"))
 line = [l for l in open(os.path.join(src, "bench_ktrace.log")) if l.startswith("{")]
 if line:
     open(os.path.join(dst, f"{tag}_bench_under_rocprof.json"), "w").write(line[-1])
 pmc = {}
 for name, sub in (("FETCH_SIZE", "pmc_fetch"), ("WRITE_SIZE", "pmc_write")):
-    f = glob.glob(os.path.join(src, sub, "*", "*counter_collection.csv"))[0]
+    f = newest(os.path.join(src, sub, "*", "*counter_collection.csv"))
     agg = collections.defaultdict(lambda: [0, 0.0])
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"].split("(")[0].replace("void ", "")
@@ -36,7 +41,7 @@ json.dump(pmc, open(os.path.join(dst, f"{tag}_pmc_hbm.json"), "w"), indent=1)
 def per_launch(counter, scale):
     n = tot = 0
     for k, v in pmc[counter].items():
-        targs = k[k.index("<") + 1:].split(",") if k.startswith("k_trace<") else []
+        targs = k[k.index("<") + 1:].split(",") if k.startswith(("k_trace<", "k_trace_stream<")) else []
         if len(targs) >= 2 and targs[1].strip() == "false":  # COUNT == false: the instantiations bench.py times
             n += v["launches"]
             tot += v["KB_total"]
