@@ -321,3 +321,35 @@ def test_gpu_bvh_build_equals_oracle_tree(P, oracle, name):
     print(name, "build ms: gpu %.2f host %.2f" % (g.stats()["build_ms"], h.stats()["build_ms"]))
     g.close()
     h.close()
+
+
+# ---------------------------------------------------------------- seeded sweep over render configurations
+@pytest.mark.parametrize("seed", range(6))
+def test_random_configs_raw_sums_bitwise(P, oracle, seed, monkeypatch):
+    """Random (scene, size, spp, depth, batching, band sharding, trace-kernel choice): the raw per-pixel sums are the
+    oracle's bit for bit whatever way the work is cut up."""
+    torch = pytest.importorskip("torch")
+    rng = np.random.default_rng(1000 + seed)
+    w, h = int(rng.integers(9, 97)), int(rng.integers(5, 61))
+    spp, depth = int(rng.integers(1, 10)), int(rng.integers(1, 11))
+    kind = ["shirley", "shirley_no_simd", "cornell", "ganesha"][int(rng.integers(0, 4))]
+    d = {"shirley": lambda: oracle.desc_shirley(w, h), "shirley_no_simd": lambda: oracle.desc_shirley(w, h, no_simd=True),
+         "cornell": lambda: oracle.desc_cornell(w, h), "ganesha": lambda: oracle.desc_ganesha_like(w, h, n_target=4000)}[kind]()
+    monkeypatch.setenv("PTX_TRACE_STREAM", str(int(rng.integers(0, 2))))  # both trace kernels on every kind of scene
+    monkeypatch.setenv("PTX_STREAMS", str(int(rng.integers(1, 3))))
+    o_scene = oracle.Scene(d.ptr, d)
+    g_scene = P.Scene(d.ptr, 0, keepalive=d)
+    c = o_scene.render(w, h, spp, depth, threads=8, want_raw=True)
+    ppb = int(rng.integers(0, spp + 1))  # 0 = the library's own choice
+    band_rows, world = int(rng.choice([1, 3, 8, 32])), int(rng.integers(1, 4))
+    full = torch.zeros((h, w, 3), dtype=torch.float64, device="cuda:0")
+    for rank in range(world):
+        pr = P.render_params(w, h, spp, depth, band_rows=band_rows, band_first=rank, band_step=world, passes_per_batch=ppb)
+        rows = P.local_rows(pr)
+        part = torch.zeros((max(rows, 1), w, 3), dtype=torch.float64, device="cuda:0")
+        g_scene.render_raw_device(pr, part.data_ptr())
+        for k in range(rows):
+            full[P.global_row(pr, k)] = part[k]
+    nbad = int((bits(full.cpu().numpy()) != bits(c["raw"])).sum())
+    assert nbad == 0, f"{kind} {w}x{h} spp {spp} depth {depth} ppb {ppb} bands {band_rows}/{world}: {nbad} raw values differ"
+    g_scene.close()
