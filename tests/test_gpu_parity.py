@@ -336,7 +336,7 @@ def test_random_configs_raw_sums_bitwise(P, oracle, seed, monkeypatch):
     d = {"shirley": lambda: oracle.desc_shirley(w, h), "shirley_no_simd": lambda: oracle.desc_shirley(w, h, no_simd=True),
          "cornell": lambda: oracle.desc_cornell(w, h), "ganesha": lambda: oracle.desc_ganesha_like(w, h, n_target=4000)}[kind]()
     monkeypatch.setenv("PTX_TRACE_STREAM", str(int(rng.integers(0, 2))))  # both trace kernels on every kind of scene
-    monkeypatch.setenv("PTX_STREAMS", str(int(rng.integers(1, 3))))
+    monkeypatch.setenv("PTX_STREAMS", str(int(rng.integers(1, 5))))  # batches in flight
     o_scene = oracle.Scene(d.ptr, d)
     g_scene = P.Scene(d.ptr, 0, keepalive=d)
     c = o_scene.render(w, h, spp, depth, threads=8, want_raw=True)
