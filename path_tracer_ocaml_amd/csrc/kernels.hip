@@ -1091,6 +1091,9 @@ __device__ __forceinline__ uint32_t pt_block_sort_by_category(int key, uint32_t*
 #ifndef PT_SHADE_BLOCK
 #define PT_SHADE_BLOCK 512 /* <= 512: the category / bin tables are scanned by one wave (<= 64 entries) */
 #endif
+#ifndef PT_SHADE_PREFETCH
+#define PT_SHADE_PREFETCH 1
+#endif
 #ifndef PT_SHADE_WAVES
 #define PT_SHADE_WAVES 4
 #endif
@@ -1108,11 +1111,29 @@ __global__ __launch_bounds__(PT_SHADE_BLOCK, PT_SHADE_WAVES) void k_shade(PtScen
   const uint32_t n = PRIMARY ? n_primary : *q.count;
   const double pi = 3.14159265358979323846;
 
-  for (uint32_t base_i = blockIdx.x * blockDim.x; base_i < n; base_i += gridDim.x * blockDim.x) {
+  /* The sort key of an entry is two dependent loads away (hit slot -> its category).  They are issued one
+   * iteration (category) and two iterations (slot) ahead, so the chain hides behind the previous groups' shading. */
+  const uint32_t stride = gridDim.x * blockDim.x;
+  int pf_key = PT_CAT_NONE, pf_slot = -2; /* key of this iteration's entry; slot of the next iteration's (-2: none) */
+  if (PT_SHADE_SORT && PT_SHADE_PREFETCH && !PRIMARY) {
+    const uint32_t i0 = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i0 < n) {
+      const int sl = hits.slot[i0];
+      pf_key = sl < 0 ? PT_CAT_MISS : (int)sc.slot_cat[sl];
+    }
+    if ((unsigned long long)i0 + stride < n) pf_slot = hits.slot[i0 + stride];
+  }
+  for (uint32_t base_i = blockIdx.x * blockDim.x; base_i < n; base_i += stride) {
     uint32_t i = base_i + threadIdx.x;
     if (PT_SHADE_SORT && !PRIMARY) {
       int key = PT_CAT_NONE;
-      if (i < n) {
+      if (PT_SHADE_PREFETCH) {
+        key = pf_key;
+        /* next iteration's key from the slot fetched an iteration ago; the slot after that */
+        pf_key = pf_slot == -2 ? PT_CAT_NONE : (pf_slot < 0 ? PT_CAT_MISS : (int)sc.slot_cat[pf_slot]);
+        const unsigned long long i2 = (unsigned long long)i + 2ull * stride;
+        pf_slot = i2 < n ? hits.slot[i2] : -2;
+      } else if (i < n) {
         const int sl = hits.slot[i];
         key = sl < 0 ? PT_CAT_MISS : (int)sc.slot_cat[sl];
       }
