@@ -289,6 +289,14 @@ int32_t ptx_lds_sample(int32_t device, int32_t dimension, int64_t n, const int32
 int32_t ptx_math_eval(int32_t device, int32_t fn, int64_t n, const double* a, const double* b,
                       double* out);
 
+/* Diagnostic (parity tooling, tools/diag_scatter.py): the state of the listed paths after ONE segment (camera ray,
+ * trace, shade of bounce 0) -- alive_out[i] = 1 with ray_out[6i..] = (origin, direction) and attn_out[3i..] when
+ * sample i scattered, 0 when it terminated.  This is how the hipcc miscompile of the dielectric branch was isolated
+ * (DESIGN.md section 2).  Not part of the rendering path; needs max_bounces >= 2. */
+int32_t ptx_debug_first_scatter(ptx_scene* scene, const ptx_render_params* params, int64_t n, const int32_t* xs,
+                                const int32_t* ys, const int32_t* passes, double* ray_out, double* attn_out,
+                                int32_t* alive_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -32,7 +32,7 @@ EXPORTS = (
     "ptx_version", "ptx_leaf_size", "ptx_last_error", "ptx_device_count", "ptx_scene_create", "ptx_scene_destroy",
     "ptx_scene_stats", "ptx_render", "ptx_local_rows", "ptx_global_row", "ptx_render_raw_device",
     "ptx_film_resolve_device", "ptx_trace_samples", "ptx_intersect_rays", "ptx_scene_tree", "ptx_lds_sample",
-    "ptx_math_eval", "ptx_ppm_render",
+    "ptx_math_eval", "ptx_ppm_render", "ptx_debug_first_scatter",
 )
 
 PROGRESS_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_int64)
