@@ -638,6 +638,11 @@ __device__ __forceinline__ PtSceneView pt_scene_view(const PtSceneDev& sc, unsig
 #ifndef PT_TRACE_BLOCK_LDS
 #define PT_TRACE_BLOCK_LDS 1024 /* workgroup size when the scene is copied to LDS (one copy per workgroup) */
 #endif
+#ifndef PT_TRACE_BLOCK_LDS_ARRAY
+#define PT_TRACE_BLOCK_LDS_ARRAY 512 /* Array_leaf kernels need ~106 VGPRs (4 waves per SIMD either way): cornell +6.6 % over 1024 */
+#endif
+#define PT_TRACE_BLOCK_OF(MODE, LDS_SCENE) \
+  ((LDS_SCENE) ? ((MODE) == PT_MODE_SIMD ? PT_TRACE_BLOCK_LDS : PT_TRACE_BLOCK_LDS_ARRAY) : PT_TRACE_BLOCK_GLOBAL)
 #ifndef PT_TRACE_LDS_WAVES
 #define PT_TRACE_LDS_WAVES 8 /* Simd_leaf only: waves per SIMD asked of the register allocator */
 #endif
@@ -648,7 +653,7 @@ template <int MODE, bool COUNT, bool PRIMARY, bool LDS_SCENE>
 /* Simd_leaf + LDS scene fits 64 VGPRs without spilling: ask for 2 x 1024-thread workgroups per CU.  The Array_leaf
  * variants (triangle / scalar-sphere code) need ~100 VGPRs: forcing 64 would spill to scratch (1.5 GB of HBM
  * writes per launch on cornell). */
-__global__ __launch_bounds__(LDS_SCENE ? PT_TRACE_BLOCK_LDS : PT_TRACE_BLOCK_GLOBAL, (LDS_SCENE && MODE == PT_MODE_SIMD) ? PT_TRACE_LDS_WAVES : PT_TRACE_GLOBAL_WAVES) void k_trace(PtSceneDev sc, PtQueue q, PtHits hits, int stack_depth,
+__global__ __launch_bounds__(PT_TRACE_BLOCK_OF(MODE, LDS_SCENE), (LDS_SCENE && MODE == PT_MODE_SIMD) ? PT_TRACE_LDS_WAVES : PT_TRACE_GLOBAL_WAVES) void k_trace(PtSceneDev sc, PtQueue q, PtHits hits, int stack_depth,
                                                PtCounters* counters, PtGenParams g, const double* __restrict__ alpha,
                                                uint32_t n_primary) {
   extern __shared__ __attribute__((aligned(64))) unsigned char lds_raw[];
@@ -725,7 +730,7 @@ __global__ __launch_bounds__(LDS_SCENE ? PT_TRACE_BLOCK_LDS : PT_TRACE_BLOCK_GLO
 #define PT_STREAM_WALK_MIN 16
 #endif
 template <int MODE, bool COUNT, bool LDS_SCENE>
-__global__ __launch_bounds__(LDS_SCENE ? PT_TRACE_BLOCK_LDS : PT_TRACE_BLOCK_GLOBAL, PT_TRACE_GLOBAL_WAVES) void k_trace_stream(
+__global__ __launch_bounds__(PT_TRACE_BLOCK_OF(MODE, LDS_SCENE), PT_TRACE_GLOBAL_WAVES) void k_trace_stream(
     PtSceneDev sc, PtQueue q, PtHits hits, int stack_depth, PtCounters* counters) {
   extern __shared__ __attribute__((aligned(64))) unsigned char lds_raw[];
   const int lane = pt_lane();
