@@ -148,7 +148,8 @@ def main():
     params = P.render_params(w, h, spp, depth, band_rows=D.BAND_ROWS, band_first=rank, band_step=world,
                              time_kernels=True, passes_per_batch=args.passes_per_batch)
     rows = P.local_rows(params)
-    part = torch.zeros((rows, w, 3), dtype=torch.float64, device=dev)
+    # padded to the largest rank's row count, so the gather sends this buffer as it is (no per-step pad copy)
+    part = torch.zeros((max(rows, D.max_local_rows(h, world, D.BAND_ROWS)), w, 3), dtype=torch.float64, device=dev)
     rgb = torch.zeros((h, w, 3), dtype=torch.float64, device=dev) if rank == 0 else None
     stream = torch.cuda.current_stream().cuda_stream
 
