@@ -345,15 +345,12 @@ struct PtTraverser {
    * stack (far children only) lives in LDS, one column per lane (conflict-free ds_write / ds_read).  A far child's
    * bbox is tested when it is POPPED, against the closest hit so far -- exactly the t_max the reference's recursion
    * passes (shape_tree.ml:210-216). */
-  __device__ __forceinline__ void node_step(const PtSceneView& sv, StackT* stack, unsigned long long& c_nodes,
-                                            unsigned long long& c_prims) {
+  /* Bbox.is_hit of `nd` against the closest hit so far + the node's links (a, b, real slot count) */
+  __device__ __forceinline__ bool test_box(const PtSceneView& sv, uint32_t nd, uint32_t& na, uint32_t& nb, uint32_t& n_real) const {
     const double t_min = 0.0;
-    if (COUNT && (PT_DIAG == 0 || (PT_DIAG <= 2 && !ORIGIN_ZERO))) c_nodes++;
-    bool descend = false;
     bool hit;
-    uint32_t na, nb, n_real;
     if (SWZ) {
-      const unsigned char* nbase = sv.swz_nodes + (size_t)node * PT_SWZ_NODE_BYTES;
+      const unsigned char* nbase = sv.swz_nodes + (size_t)nd * PT_SWZ_NODE_BYTES;
       const uint2 links = *(const uint2*)(nbase + 72);
       na = links.x;
       nb = links.y;
@@ -376,12 +373,21 @@ struct PtTraverser {
         hit = __builtin_fmax(t_min, a) <= __builtin_fmin(r.t, b);
       }
     } else {
-      const PtNode* np = sv.nodes + node;
+      const PtNode* np = sv.nodes + nd;
       hit = exact_slab ? pt_slab_hit_exact(np->mn, o, inv, t_min, r.t) : pt_slab_hit_fast<ORIGIN_ZERO>(np->mn, o, inv, t_min, r.t);
       na = np->a;
       nb = np->b;
       n_real = np->pad[0];
     }
+    return hit;
+  }
+
+  __device__ __forceinline__ void node_step(const PtSceneView& sv, StackT* stack, unsigned long long& c_nodes,
+                                            unsigned long long& c_prims) {
+    if (COUNT && (PT_DIAG == 0 || (PT_DIAG <= 2 && !ORIGIN_ZERO))) c_nodes++;
+    bool descend = false;
+    uint32_t na, nb, n_real;
+    const bool hit = test_box(sv, node, na, nb, n_real);
     if (hit) {
       const uint32_t axis = nb >> 30;
       if (axis == PT_NODE_LEAF_AXIS) {
@@ -568,6 +574,82 @@ __device__ __forceinline__ PtTraceResult pt_trace_ray(const PtSceneDev& sc, cons
   return tr.r;
 }
 
+/* Camera rays: the 64 rays of a wave are one 8x8 pixel tile of one pass, so they walk the tree TOGETHER -- one
+ * shared stack of (node, lane mask) instead of 64 private ones.  A ray's own sequence of box tests and packet tests
+ * is exactly pt_trace_ray's: its child order depends only on the signs of its direction (shape_tree.ml:201,209), the
+ * wave is split into groups of equal signs (almost always one), a ray takes part in a node only if it hit the parent,
+ * and a far child is tested when popped, against each ray's own closest hit.  What changes is the cost: node and
+ * packet addresses are wave-uniform (LDS broadcasts, scalar control flow), no per-lane stack traffic, and the
+ * packet loop runs in lockstep.  wstack: 3 words per level, shared by the wave. */
+#ifndef PT_PRIMARY_PACKET
+#define PT_PRIMARY_PACKET 1
+#endif
+template <int MODE, bool COUNT, bool SWZ>
+__device__ __forceinline__ PtTraceResult pt_trace_packet(const PtSceneDev& sc, const PtSceneView& sv, uint32_t* wstack,
+                                                         bool valid, V3 d, unsigned long long& c_nodes,
+                                                         unsigned long long& c_prims, unsigned long long& c_floor) {
+  const int lane = pt_lane();
+  PtTraverser<MODE, COUNT, true, uint32_t, SWZ> tr;
+  unsigned long long no_count = 0; /* lanes without a sample run begin() on a dummy ray: keep them out of the counters */
+  tr.begin(sc, sv, v3(0.0, 0.0, 0.0), valid ? d : v3(0.0, 0.0, -1.0), valid ? c_floor : no_count);
+  unsigned long long remaining = __ballot(valid && tr.walking);
+  while (remaining != 0) {
+    /* the lanes that share the first remaining lane's direction signs */
+    const uint32_t d0 = (uint32_t)__builtin_amdgcn_readlane((int)tr.dirs, __ffsll((long long)remaining) - 1);
+    unsigned long long m = __ballot(tr.dirs == d0) & remaining;
+    remaining &= ~m;
+    uint32_t node = 0;
+    int sp = 0;
+    for (;;) {
+      const bool act = (m >> lane) & 1ull;
+      uint32_t na = 0, nb = 0, n_real = 0;
+      bool hit = false;
+      if (act) {
+        if (COUNT) c_nodes++;
+        hit = tr.test_box(sv, node, na, nb, n_real);
+      }
+      const unsigned long long hm = __ballot(hit);
+      bool descended = false;
+      if (hm != 0) {
+        const int src = __ffsll((long long)hm) - 1; /* the links are the node's: the same in every lane that read them */
+        const uint32_t ua = (uint32_t)__builtin_amdgcn_readlane((int)na, src);
+        const uint32_t ub = (uint32_t)__builtin_amdgcn_readlane((int)nb, src);
+        const uint32_t axis = ub >> 30;
+        if (axis == PT_NODE_LEAF_AXIS) {
+          if (hit) {
+            tr.leaf_first = (int)ua;
+            tr.leaf_n = (int)n_real;
+            if (COUNT) c_prims += (unsigned long long)(ub & 0x3fffffffu);
+            tr.packet(sv, c_nodes, c_floor);
+          }
+        } else {
+          const uint32_t lhs = ua, rhs = ub & 0x3fffffffu;
+          const bool lhs_first = (d0 >> axis) & 1u;
+          if (lane == 0) {
+            wstack[3 * sp] = lhs_first ? rhs : lhs;
+            wstack[3 * sp + 1] = (uint32_t)hm;
+            wstack[3 * sp + 2] = (uint32_t)(hm >> 32);
+          }
+          ++sp;
+          node = lhs_first ? lhs : rhs;
+          m = hm;
+          descended = true;
+        }
+      }
+      if (!descended) {
+        if (sp == 0) break;
+        --sp;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        node = (uint32_t)__builtin_amdgcn_readfirstlane((int)wstack[3 * sp]);
+        m = (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)wstack[3 * sp + 1]) |
+            ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)wstack[3 * sp + 2]) << 32);
+      }
+    }
+  }
+  return tr.r;
+}
+
 /* Where this workgroup traverses from.  LDS_SCENE: the whole tree and every leaf packet are first copied into LDS
  * behind the traversal stacks (nodes expanded to the swizzled image on the way); ends with a __syncthreads(). */
 template <int MODE, bool LDS_SCENE, typename StackT>
@@ -669,6 +751,30 @@ __global__ __launch_bounds__(PT_TRACE_BLOCK_OF(MODE, LDS_SCENE), (LDS_SCENE && M
   const uint32_t nwaves = gridDim.x * waves_per_block;
   unsigned long long c_nodes = 0, c_prims = 0, c_floor = 0, c_seg = 0;
 
+  if (PRIMARY && PT_PRIMARY_PACKET && LDS_SCENE) { /* from HBM/L2 one shared node fetch per step serialises the latency: -3 % */
+    /* the wave's private stack area (stack_depth x 64 entries) holds the shared (node, mask) stack: 12 B per level */
+    uint32_t* wstack = (uint32_t*)((StackT*)lds_raw + (size_t)wave_in_block * stack_depth * PT_WAVE);
+    for (uint32_t chunk = gwave; (unsigned long long)chunk * PT_WAVE < n; chunk += nwaves) {
+      const uint32_t i = chunk * PT_WAVE + lane;
+      bool valid = i < n;
+      V3 d = v3(0.0, 0.0, -1.0);
+      if (valid) {
+        const PtPrimarySample ps = pt_primary_decode(g, i);
+        valid = ps.valid;
+        if (valid) d = pt_primary_dir(sc, g, ps, alpha);
+      }
+      if (COUNT && valid) c_seg++;
+      const PtTraceResult r = pt_trace_packet<MODE, COUNT, LDS_SCENE>(sc, sv, wstack, valid, d, c_nodes, c_prims, c_floor);
+      if (valid) {
+        hits.t[i] = r.t;
+        hits.slot[i] = r.slot;
+        if (MODE == PT_MODE_ARRAY && sc.has_triangles) {
+          hits.u[i] = r.u;
+          hits.v[i] = r.v;
+        }
+      }
+    }
+  } else
   for (uint32_t chunk = gwave; (unsigned long long)chunk * PT_WAVE < n; chunk += nwaves) {
     const uint32_t i = chunk * PT_WAVE + lane;
     if (i >= n) continue;
