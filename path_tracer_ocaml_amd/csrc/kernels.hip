@@ -600,26 +600,64 @@ __device__ __forceinline__ PtTraceResult pt_trace_packet(const PtSceneDev& sc, c
     remaining &= ~m;
     uint32_t node = 0;
     int sp = 0;
+    bool act = (m >> lane) & 1ull; /* this lane takes part in `node` */
     for (;;) {
-      const bool act = (m >> lane) & 1ull;
-      uint32_t na = 0, nb = 0, n_real = 0;
+      /* the node's links: one address for the whole wave */
+      uint32_t ua, ub, n_real;
+      if (SWZ) {
+        const unsigned char* nbase = sv.swz_nodes + (size_t)node * PT_SWZ_NODE_BYTES;
+        ua = (uint32_t)__builtin_amdgcn_readfirstlane((int)*(const uint32_t*)(nbase + 72));
+        ub = (uint32_t)__builtin_amdgcn_readfirstlane((int)*(const uint32_t*)(nbase + 76));
+        n_real = (uint32_t)__builtin_amdgcn_readfirstlane((int)*(const uint32_t*)(nbase + 80));
+      } else {
+        const PtNode* np = sv.nodes + node;
+        ua = (uint32_t)__builtin_amdgcn_readfirstlane((int)np->a);
+        ub = (uint32_t)__builtin_amdgcn_readfirstlane((int)np->b);
+        n_real = (uint32_t)__builtin_amdgcn_readfirstlane((int)np->pad[0]);
+      }
       bool hit = false;
       if (act) {
         if (COUNT) c_nodes++;
-        hit = tr.test_box(sv, node, na, nb, n_real);
+        uint32_t x0, x1, x2;
+        hit = tr.test_box(sv, node, x0, x1, x2);
       }
       const unsigned long long hm = __ballot(hit);
       bool descended = false;
       if (hm != 0) {
-        const int src = __ffsll((long long)hm) - 1; /* the links are the node's: the same in every lane that read them */
-        const uint32_t ua = (uint32_t)__builtin_amdgcn_readlane((int)na, src);
-        const uint32_t ub = (uint32_t)__builtin_amdgcn_readlane((int)nb, src);
         const uint32_t axis = ub >> 30;
         if (axis == PT_NODE_LEAF_AXIS) {
-          if (hit) {
+          if (COUNT && hit) c_prims += (unsigned long long)(ub & 0x3fffffffu);
+          if (MODE == PT_MODE_SIMD) {
+            /* spheres_intersect_aux (lib.rs:102-178) in lockstep: slot k of the packet for every ray that hit the
+             * leaf's box; the roots only where a ray's discriminant is >= +0 (same order per ray as packet()) */
+            const double t_min = 0.0;
+            for (uint32_t k = 0; k < n_real; ++k) {
+              const double* sp4 = sv.sph + (size_t)(ua + k) * 4;
+              const double fx = sp4[0], fy = sp4[1], fz = sp4[2]; /* f = center - origin, origin = (+0, +0, +0) */
+              const double r2 = sp4[3] * sp4[3];
+              const double bp = pt_fma(fx, tr.d.x, pt_fma(fy, tr.d.y, fz * tr.d.z));
+              const double bp_over_a = bp * tr.one_over_a;
+              const double wx = pt_fma(tr.d.x, bp_over_a, -fx);
+              const double wy = pt_fma(tr.d.y, bp_over_a, -fy);
+              const double wz = pt_fma(tr.d.z, bp_over_a, -fz);
+              const double disc = r2 - pt_fma(wx, wx, pt_fma(wy, wy, wz * wz));
+              const bool found = hit && (disc == disc) && !pt_signbit(disc);
+              if (__ballot(found) != 0) {
+                if (found) {
+                  const double c = pt_fma(fx, fx, pt_fma(fy, fy, fz * fz)) - r2;
+                  const double q_rhs = pt_sqrt(tr.qa * disc);
+                  const double qq = pt_signbit(bp) ? (bp - q_rhs) : (bp + q_rhs);
+                  const double t = pt_signbit(c) ? (qq * tr.one_over_a) : (c / qq);
+                  if (!(t < t_min) && t <= tr.r.t) {
+                    tr.r.t = t;
+                    tr.r.slot = (int)(ua + k);
+                  }
+                }
+              }
+            }
+          } else if (hit) {
             tr.leaf_first = (int)ua;
             tr.leaf_n = (int)n_real;
-            if (COUNT) c_prims += (unsigned long long)(ub & 0x3fffffffu);
             tr.packet(sv, c_nodes, c_floor);
           }
         } else {
@@ -632,7 +670,7 @@ __device__ __forceinline__ PtTraceResult pt_trace_packet(const PtSceneDev& sc, c
           }
           ++sp;
           node = lhs_first ? lhs : rhs;
-          m = hm;
+          act = hit;
           descended = true;
         }
       }
@@ -642,8 +680,9 @@ __device__ __forceinline__ PtTraceResult pt_trace_packet(const PtSceneDev& sc, c
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
         node = (uint32_t)__builtin_amdgcn_readfirstlane((int)wstack[3 * sp]);
-        m = (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)wstack[3 * sp + 1]) |
-            ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)wstack[3 * sp + 2]) << 32);
+        const unsigned long long pm = (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)wstack[3 * sp + 1]) |
+                                      ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)wstack[3 * sp + 2]) << 32);
+        act = (pm >> lane) & 1ull;
       }
     }
   }
