@@ -353,3 +353,20 @@ def test_random_configs_raw_sums_bitwise(P, oracle, seed, monkeypatch):
     nbad = int((bits(full.cpu().numpy()) != bits(c["raw"])).sum())
     assert nbad == 0, f"{kind} {w}x{h} spp {spp} depth {depth} ppb {ppb} bands {band_rows}/{world}: {nbad} raw values differ"
     g_scene.close()
+
+
+@pytest.mark.parametrize("num_bins,cutoff", [(4, 4), (8, 8), (16, 2), (64, 12)])
+def test_gpu_bvh_build_other_bin_counts_and_cutoffs(P, oracle, num_bins, cutoff):
+    """?num_bins and Leaf.length_cutoff other than the scenes' defaults (the photon map uses 8 / 8, shape_tree.ml:252)."""
+    import ctypes as C
+    from path_tracer_ocaml_amd import abi
+    od = oracle.desc_ganesha_like(192, 108, 9000)
+    d = abi.SceneDesc()
+    C.memmove(C.byref(d), od.ptr, C.sizeof(d))
+    d.num_bins, d.length_cutoff = num_bins, cutoff
+    ob, oi, oo = oracle.Scene(C.pointer(d), od).tree()
+    d.reserved = 2  # GPU builder
+    g = P.Scene(d, 0, keepalive=od)
+    gb, gi, go = g.tree()
+    assert np.array_equal(bits(gb), bits(ob)) and np.array_equal(gi, oi) and np.array_equal(go, oo)
+    g.close()
