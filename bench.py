@@ -98,7 +98,7 @@ def cpu_baseline(workload, seconds_budget=20.0):
         "value": samples / r["ms"] * 1e-3, "unit": "Msamples/s", "cores": cores, "kind": "port",
         "sample": f"{w}x{h} spp={n_pass} of {spp} depth={depth}, same scene/camera, {cores} threads, "
                   f"{r['ms'] / 1e3:.1f} s (C restatement of the reference OCaml/Rust path, libm math)",
-    }
+    }, r["rgb"], n_pass
 
 
 def main():
@@ -250,7 +250,20 @@ def main():
         }
         if not args.no_cpu_baseline and world == 1:
             try:
-                out["cpu_baseline"] = cpu_baseline(args.workload, args.cpu_seconds)
+                out["cpu_baseline"], cpu_rgb, cpu_spp = cpu_baseline(args.workload, args.cpu_seconds)
+                # the metric's third part: per-pixel relative L-inf of the post-gamma framebuffer against the CPU
+                # reference, at the sample count the CPU leg rendered (untimed; the oracle is only the checker here)
+                pp = P.render_params(w, h, cpu_spp, depth)
+                g_raw = torch.zeros((h, w, 3), dtype=torch.float64, device=dev)
+                g_rgb = torch.zeros((h, w, 3), dtype=torch.float64, device=dev)
+                scene.render_raw_device(pp, g_raw.data_ptr(), stream)
+                P.film_resolve_device(local_dev, w, h, cpu_spp, g_raw.data_ptr(), g_rgb.data_ptr(), stream)
+                torch.cuda.synchronize()
+                import numpy as np
+                g = g_rgb.cpu().numpy()
+                out["parity"] = {"rel_linf_vs_cpu_ref": float(np.max(np.abs(g - cpu_rgb) / np.maximum(np.abs(cpu_rgb), 1e-3))),
+                                 "tolerance": 1e-5, "spp": cpu_spp,
+                                 "note": "CPU ref in libm math (as the OCaml runtime); in the shared pt_math mode the tests show bit-exact raw sums"}
             except Exception as e:  # the oracle is test infrastructure; its absence must not hide the GPU number
                 out["cpu_baseline"] = {"value": None, "unit": "Msamples/s", "cores": os.cpu_count(), "kind": "port",
                                        "sample": f"unavailable: {e}"}
