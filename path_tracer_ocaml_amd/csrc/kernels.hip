@@ -354,7 +354,7 @@ struct PtTraverser {
       const uint2 links = *(const uint2*)(nbase + 72);
       na = links.x;
       nb = links.y;
-      n_real = *(const uint32_t*)(nbase + 80);
+      n_real = (nb >> 15) & 0x7fffu; /* meaningful for leaves only (pt_scene_view packs it into the link word) */
       if (exact_slab) {
         const double* bx = (const double*)nbase;
         const double box6[6] = {bx[0], bx[3], bx[6], bx[1], bx[4], bx[7]};
@@ -393,7 +393,7 @@ struct PtTraverser {
       if (axis == PT_NODE_LEAF_AXIS) {
         leaf_first = (int)na;
         leaf_n = (int)n_real; /* real slots; the NaN padding (main.ml:185) can never be selected */
-        if (COUNT && PT_DIAG == 0) c_prims += (unsigned long long)(nb & 0x3fffffffu); /* Leaf.length incl. padding */
+        if (COUNT && PT_DIAG == 0) c_prims += (unsigned long long)(nb & (SWZ ? 0x7fffu : 0x3fffffffu)); /* Leaf.length incl. padding */
       } else {
         /* Branch: near child first (shape_tree.ml:209), far child deferred */
         const uint32_t lhs = na, rhs = nb & 0x3fffffffu;
@@ -608,7 +608,7 @@ __device__ __forceinline__ PtTraceResult pt_trace_packet(const PtSceneDev& sc, c
         const unsigned char* nbase = sv.swz_nodes + (size_t)node * PT_SWZ_NODE_BYTES;
         ua = (uint32_t)__builtin_amdgcn_readfirstlane((int)*(const uint32_t*)(nbase + 72));
         ub = (uint32_t)__builtin_amdgcn_readfirstlane((int)*(const uint32_t*)(nbase + 76));
-        n_real = (uint32_t)__builtin_amdgcn_readfirstlane((int)*(const uint32_t*)(nbase + 80));
+        n_real = (ub >> 15) & 0x7fffu;
       } else {
         const PtNode* np = sv.nodes + node;
         ua = (uint32_t)__builtin_amdgcn_readfirstlane((int)np->a);
@@ -626,7 +626,7 @@ __device__ __forceinline__ PtTraceResult pt_trace_packet(const PtSceneDev& sc, c
       if (hm != 0) {
         const uint32_t axis = ub >> 30;
         if (axis == PT_NODE_LEAF_AXIS) {
-          if (COUNT && hit) c_prims += (unsigned long long)(ub & 0x3fffffffu);
+          if (COUNT && hit) c_prims += (unsigned long long)(ub & (SWZ ? 0x7fffu : 0x3fffffffu));
           if (MODE == PT_MODE_SIMD) {
             /* spheres_intersect_aux (lib.rs:102-178) in lockstep: slot k of the packet for every ray that hit the
              * leaf's box; the roots only where a ray's discriminant is >= +0 (same order per ray as packet()) */
@@ -721,7 +721,8 @@ __device__ __forceinline__ PtSceneView pt_scene_view(const PtSceneDev& sc, unsig
       }
       uint32_t* w = (uint32_t*)(dst + 9);
       w[0] = src->a;
-      w[1] = src->b;
+      /* leaves: padded length | real slot count << 15 | tag, so that a visit reads one 8-byte link pair and nothing else */
+      w[1] = (src->b >> 30) == PT_NODE_LEAF_AXIS ? ((src->b & 0x7fffu) | ((src->pad[0] & 0x7fffu) << 15) | (PT_NODE_LEAF_AXIS << 30)) : src->b;
       w[2] = src->pad[0];
       w[3] = 0u;
       w[4] = 0u;
