@@ -71,6 +71,19 @@ def measured_hbm_copy_gbs(torch, dev):
     return 2.0 * a.numel() * 4 * reps / (e0.elapsed_time(e1) * 1e-3) * 1e-9
 
 
+def effective_cpus():
+    """CPUs this process may actually use: affinity mask, capped by the cgroup CPU quota (the GPU box shows 256 logical
+    CPUs but grants 16 CPUs' worth of time; more runnable threads than that only add throttling)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
 def cpu_baseline(workload, seconds_budget=20.0):
     """The oracle (C restatement of the reference CPU path, libm math like the OCaml runtime, tile-parallel
     over all host threads like integrator.ml:138-146) timed on a bounded sample of the same workload."""
@@ -83,7 +96,7 @@ def cpu_baseline(workload, seconds_budget=20.0):
     else:
         d = O.desc_ganesha_like(w, h, 150000, 7)
     s = O.Scene(d.ptr, d)
-    cores = os.cpu_count() or 1
+    cores = effective_cpus()
     O.set_math(1)
     try:
         # calibrate on 1 pass, then size the sample to the budget
@@ -265,7 +278,7 @@ def main():
                                  "tolerance": 1e-5, "spp": cpu_spp,
                                  "note": "CPU ref in libm math (as the OCaml runtime); in the shared pt_math mode the tests show bit-exact raw sums"}
             except Exception as e:  # the oracle is test infrastructure; its absence must not hide the GPU number
-                out["cpu_baseline"] = {"value": None, "unit": "Msamples/s", "cores": os.cpu_count(), "kind": "port",
+                out["cpu_baseline"] = {"value": None, "unit": "Msamples/s", "cores": effective_cpus(), "kind": "port",
                                        "sample": f"unavailable: {e}"}
         print(json.dumps(out))
     if world > 1:
