@@ -249,10 +249,16 @@ def main():
                 "peak_measured_copy": copy_gbs, "frac_of_measured": (achieved / (copy_gbs * world)) if copy_gbs else None,
                 "algorithmic_bytes_per_launch": b_trace / max(trace_launches / args.steps, 1.0),
                 "launches_per_step": trace_launches / args.steps, "avg_launch_ms": trace_ms_total / max(trace_launches, 1.0),
+                # where the algorithmic bytes are actually served from: small scenes are copied to LDS once per workgroup,
+                # so node / packet reads never reach HBM (that is how `frac` can exceed 1; `traffic` is the HBM truth)
+                "served_from": "lds" if sstats["traversal_in_lds"] else "l1/l2/hbm",
                 "pipeline": {"bytes_per_sample": b_total / samples, "achieved": b_total * args.steps / elapsed * 1e-9,
                              "frac": b_total * args.steps / elapsed * 1e-9 / (HBM_PEAK_GBS * world)},
                 # the kernel's real ceiling: f64 vector issue.  27 flop per node test (6 sub, 6 mul, 12 min/max,
                 # 2 clamps, 1 compare), 24 per packet slot (scan part), against 78.6 TFLOP/s f64 vector peak
+                **({"lds": {"achieved": achieved, "peak": 256 * 128 * 2.4 * world, "unit": "GB/s",
+                            "frac": achieved / (256 * 128 * 2.4 * world), "note": "256 CUs x 128 B/clk (8-byte reads) x 2.4 GHz"}}
+                   if sstats["traversal_in_lds"] else {}),
                 "valu_f64": {"achieved_tflops": (counts["nodes_tested"] * 27.0 + counts["prims_tested"] * 24.0) / (trace_ms_step * 1e-3) * 1e-12 if trace_ms_step > 0 else 0.0,
                              "peak_tflops": 78.6 * world},
             },

@@ -161,7 +161,9 @@ typedef struct ptx_stats {
   double kernel_ms[PTX_N_KERNELS]; /* summed HIP-event time per kernel kind, if time_kernels */
   int64_t kernel_launches[PTX_N_KERNELS];
   int32_t tree_nodes, tree_depth, tree_leaves, leaf_slots;
-  double build_ms; /* host BVH build + upload at ptx_scene_create */
+  double build_ms; /* BVH build + upload at ptx_scene_create */
+  int32_t traversal_in_lds; /* 1: tree + leaf packets fit the per-workgroup LDS copy; 0: traversed from HBM / L2 */
+  int32_t bvh_built_on_gpu; /* 1: csrc/bvh_build_gpu.inc built the tree, 0: the host builder (same tree) */
 } ptx_stats;
 
 /* ---- progressive photon mapping (progressive-photon-map/src/progressive_photon_map.ml) ---- */

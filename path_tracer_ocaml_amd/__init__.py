@@ -114,6 +114,7 @@ def stats_dict(st):
         "kernel_launches": {n: st.kernel_launches[i] for i, n in enumerate(abi.PTX_KERNEL_NAMES)},
         "tree_nodes": st.tree_nodes, "tree_depth": st.tree_depth, "tree_leaves": st.tree_leaves,
         "leaf_slots": st.leaf_slots, "build_ms": st.build_ms,
+        "traversal_in_lds": bool(st.traversal_in_lds), "bvh_built_on_gpu": bool(st.bvh_built_on_gpu),
     }
 
 

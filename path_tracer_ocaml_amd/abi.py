@@ -65,7 +65,7 @@ class Stats(C.Structure):
         ("floor_tested", C.c_int64), ("render_ms", C.c_double),
         ("kernel_ms", C.c_double * PTX_N_KERNELS), ("kernel_launches", C.c_int64 * PTX_N_KERNELS),
         ("tree_nodes", C.c_int32), ("tree_depth", C.c_int32), ("tree_leaves", C.c_int32), ("leaf_slots", C.c_int32),
-        ("build_ms", C.c_double),
+        ("build_ms", C.c_double), ("traversal_in_lds", C.c_int32), ("bvh_built_on_gpu", C.c_int32),
     ]
 
 
