@@ -1,0 +1,50 @@
+"""bench.py's host-side pieces that need no GPU: the algorithmic-bytes formula of SURVEY.md section 8(d), the CPU share
+detection, the workload table (BASELINE.json configs), and the refusal to run without a GPU (no CPU fallback)."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bench():
+    sys.path.insert(0, ROOT)
+    import bench
+    return bench
+
+
+def test_algorithmic_bytes_formula():
+    b = _bench()
+    st = {"samples": 1000, "segments": 2500, "nodes_tested": 50000, "prims_tested": 24000, "floor_tested": 0}
+    total, trace = b.algorithmic_bytes(st, spp=10, triangles=False)
+    assert trace == 50000 * 64 + 24000 * 32 + 2500 * 64
+    assert total == 1000 * 24 / 10 + 50000 * 64 + 24000 * 32 + 2500 * 192
+    st["floor_tested"] = 100
+    total_t, _ = b.algorithmic_bytes(st, spp=10, triangles=True)
+    assert total_t == 1000 * 24 / 10 + 50000 * 64 + (24000 + 100) * 84 + 2500 * 192
+
+
+def test_workloads_are_the_baseline_configs():
+    b = _bench()
+    cfg = json.load(open(os.path.join(ROOT, "BASELINE.json")))
+    assert "north_star" in cfg
+    assert b.WORKLOADS["shirley_1080p_spp64_d8"] == ("shirley", 1920, 1080, 64, 8)   # configs[1], the headline
+    assert b.WORKLOADS["shirley_600x300_spp32_d8"] == ("shirley", 600, 300, 32, 8)    # configs[0], the README command
+    assert b.WORKLOADS["cornell_1024_spp256_d16"][1:] == (1024, 1024, 256, 16)
+    assert b.WORKLOADS["shirley_4k_spp256_d8"][1:] == (3840, 2160, 256, 8)
+    assert b.HBM_PEAK_GBS == 8000.0
+
+
+def test_effective_cpus_is_sane():
+    n = _bench().effective_cpus()
+    assert 1 <= n <= (os.cpu_count() or 1)
+
+
+def test_bench_refuses_to_run_without_a_gpu():
+    import torch
+    if torch.cuda.is_available():
+        return  # on the GPU box this is covered by running the benchmark itself
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "0"], capture_output=True, text=True)
+    assert r.returncode != 0
+    assert "no CPU fallback" in (r.stderr + r.stdout)
