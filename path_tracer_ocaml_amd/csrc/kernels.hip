@@ -1172,6 +1172,7 @@ __device__ __forceinline__ uint32_t pt_block_append(uint32_t* counter, bool keep
  * so the waves of the next trace launch walk the tree in the same child order.  One atomic per iteration.
  * lds: PT_APPEND_BINS * (blockDim/64) + 1 words (<= 65). */
 static_assert(PT_APPEND_BINS == 1 || PT_APPEND_BINS == 8, "the bin key is the direction octant (0..7)");
+template <bool TRAILING_SYNC>
 __device__ __forceinline__ uint32_t pt_block_append_binned(uint32_t* counter, bool keep, int key, uint32_t* lds) {
   const int lane = pt_lane();
   const int wave = (int)(threadIdx.x >> 6), nw = (int)(blockDim.x >> 6);
@@ -1199,7 +1200,8 @@ __device__ __forceinline__ uint32_t pt_block_append_binned(uint32_t* counter, bo
   }
   __syncthreads();
   const uint32_t dst = lds[key * nw + wave] + rank;
-  __syncthreads();
+  /* protects `lds` against the NEXT call; not needed when other workgroup barriers separate the calls anyway */
+  if (TRAILING_SYNC) __syncthreads();
   return dst;
 }
 
@@ -1387,7 +1389,8 @@ __global__ __launch_bounds__(PT_SHADE_BLOCK, PT_SHADE_WAVES) void k_shade(PtScen
     }
 #if PT_APPEND_BINS > 1
     const int octant = (n_d.x >= 0.0 ? 1 : 0) | (n_d.y >= 0.0 ? 2 : 0) | (n_d.z >= 0.0 ? 4 : 0);
-    const uint32_t dst = pt_block_append_binned(out.count, keep, octant, lds_bins);
+    /* with the category sort on, its three barriers separate one append from the next */
+    const uint32_t dst = pt_block_append_binned<!(PT_SHADE_SORT && !PRIMARY)>(out.count, keep, octant, lds_bins);
 #else
     const uint32_t dst = pt_block_append(out.count, keep, lds_append);
 #endif
