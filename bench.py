@@ -6,8 +6,8 @@ A "step" = one complete render of that image: generate -> (trace, shade) x 8 -> 
 sample, gather of the raw sums to rank 0 (N > 1) and the film filter + gamma.  The scene (BVH, packets,
 materials) is resident in HBM before the timed region; the framebuffer stays on the device.
 
-N > 1: the SAME image, rows dealt to ranks in interleaved 32-row bands (strong scaling), one
-torch.distributed gather (RCCL over xGMI) of the raw sums per step.
+N > 1: the SAME image, rows dealt to ranks in interleaved 8-row bands (strong scaling), one group of
+point-to-point sends (RCCL over xGMI) of the raw sums into rank 0 per step; the film reads the bands in place.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with "roofline" and "cpu_baseline".
 """
@@ -160,17 +160,19 @@ def main():
 
     params = P.render_params(w, h, spp, depth, band_rows=D.BAND_ROWS, band_first=rank, band_step=world,
                              time_kernels=True, passes_per_batch=args.passes_per_batch)
-    rows = P.local_rows(params)
-    # padded to the largest rank's row count, so the gather sends this buffer as it is (no per-step pad copy)
-    part = torch.zeros((max(rows, D.max_local_rows(h, world, D.BAND_ROWS)), w, 3), dtype=torch.float64, device=dev)
+    # every buffer of the step is allocated here, once: each rank renders into its send buffer (rank 0 into slice 0
+    # of the receive buffer), the peers' bands arrive in place, and the film kernel reads the banded layout as it is
+    bg = D.BandGather(h, w, rank, world, dev)
+    part = bg.part
     rgb = torch.zeros((h, w, 3), dtype=torch.float64, device=dev) if rank == 0 else None
     stream = torch.cuda.current_stream().cuda_stream
 
     def step():
         st = scene.render_raw_device(params, part.data_ptr(), stream)
-        full = D.gather_raw_to_root(part, h, w, rank, world, D.BAND_ROWS)
+        gathered = bg.gather()
         if rank == 0:
-            P.film_resolve_device(local_dev, w, h, spp, full.data_ptr(), rgb.data_ptr(), stream)
+            P.film_resolve_banded_device(local_dev, w, h, spp, gathered.data_ptr(), world, D.BAND_ROWS, bg.pad_rows,
+                                         rgb.data_ptr(), stream)
         return st
 
     def fence():

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define PTX_ABI_VERSION 1
+#define PTX_ABI_VERSION 2
 
 /* ---- materials: Material.t, path_tracer/src/material.ml:3-14 ---- */
 #define PTX_MAT_LAMBERTIAN 0 /* Lambertian of Texture.t */
@@ -141,7 +141,12 @@ typedef struct ptx_render_params {
   int32_t time_kernels;
   /* samples per wavefront batch in passes; 0 = library default */
   int32_t passes_per_batch;
-  int32_t reserved[2];
+  /* ptx_render only: GPUs of this node to spread the image over, inside this one process (SURVEY section 8 B3 / E;
+   * the reference's Domainslib pool over tiles, integrator.ml:136-151, becomes one host thread per device over
+   * interleaved row bands).  0 or 1 = the scene's own device only.  Devices used: the scene's, then the following
+   * ordinals (mod ptx_device_count()); replicas of the scene are made on first use and kept with the handle. */
+  int32_t n_gpus;
+  int32_t reserved;
 } ptx_render_params;
 
 #define PTX_KERNEL_GENERATE 0
@@ -226,6 +231,23 @@ int32_t ptx_scene_stats(const ptx_scene* scene, ptx_stats* out);
 int32_t ptx_render(ptx_scene* scene, const ptx_render_params* params, double* rgb_out,
                    ptx_stats* stats, ptx_progress_fn progress, void* user);
 
+/* The same render over several GPUs of one node inside ONE process, for hosts that are a single process (the OCaml
+ * executable, the C++ CLI): scenes[k] is a replica of the scene on the k-th device (ptx_scene_replicate; scenes[0]
+ * may be the original), image rows are dealt in interleaved bands of params->band_rows rows (0 -> 8), one host
+ * thread per scene renders its bands (integrator.ml:138-146), the raw sums travel to scenes[0]'s device as one
+ * peer-to-peer copy per replica (xGMI), and the film pass runs there.  n_scenes = 1 is ptx_render bit for bit; any
+ * n_scenes gives bit-identical raw sums (the sampler offset depends only on the global pixel, integrator.ml:98).
+ * progress is invoked on the CALLING thread only.  Scenes may share a device (tests on a one-GPU box). */
+int32_t ptx_render_multi(ptx_scene* const* scenes, int32_t n_scenes, const ptx_render_params* params,
+                         double* rgb_out, ptx_stats* stats, ptx_progress_fn progress, void* user);
+
+/* A replica of `scene` on HIP device `device`: the flattened tree / slots / materials the original kept on the host
+ * are uploaded again (no second BVH build).  Independent handle: destroy it with ptx_scene_destroy. */
+ptx_scene* ptx_scene_replicate(const ptx_scene* scene, int32_t device);
+
+/* Frees the calling thread's cached GPU-BVH-builder buffers (they otherwise live as long as the thread). */
+void ptx_release_workspaces(void);
+
 /* Device-resident form, for one rank of a multi-GPU job and for benchmarking with no
  * PCIe traffic in the timed region.  d_raw_out is DEVICE memory holding this rank's
  * rows compactly: ptx_local_rows(params) * width * 3 doubles of raw per-pixel radiance
@@ -244,6 +266,13 @@ int32_t ptx_render_raw_device(ptx_scene* scene, const ptx_render_params* params,
 int32_t ptx_film_resolve_device(int32_t device, int32_t width, int32_t height,
                                 int32_t samples_per_pixel, const double* d_raw_full,
                                 double* d_rgb_out, void* stream);
+
+/* The film pass reading the GATHERED multi-rank layout in place: d_gathered is DEVICE memory
+ * [n_ranks][pad_rows][width][3], slice r = rank r's compact rows exactly as ptx_render_raw_device wrote them with
+ * band_first = r, band_step = n_ranks, band_rows (pad_rows >= every rank's ptx_local_rows).  No un-permute copy. */
+int32_t ptx_film_resolve_banded_device(int32_t device, int32_t width, int32_t height, int32_t samples_per_pixel,
+                                       const double* d_gathered, int32_t n_ranks, int32_t band_rows, int32_t pad_rows,
+                                       double* d_rgb_out, void* stream);
 
 /* Per-sample radiance for explicit (x, y, pass) triples -- the value Integrator's
  * trace_path returns (integrator.ml:106).  Host in / host out, n*3 doubles.

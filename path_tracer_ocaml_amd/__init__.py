@@ -32,7 +32,8 @@ EXPORTS = (
     "ptx_version", "ptx_leaf_size", "ptx_last_error", "ptx_device_count", "ptx_scene_create", "ptx_scene_destroy",
     "ptx_scene_stats", "ptx_render", "ptx_local_rows", "ptx_global_row", "ptx_render_raw_device",
     "ptx_film_resolve_device", "ptx_trace_samples", "ptx_intersect_rays", "ptx_scene_tree", "ptx_lds_sample",
-    "ptx_math_eval", "ptx_ppm_render", "ptx_debug_first_scatter",
+    "ptx_math_eval", "ptx_ppm_render", "ptx_debug_first_scatter", "ptx_render_multi", "ptx_scene_replicate",
+    "ptx_film_resolve_banded_device", "ptx_release_workspaces",
 )
 
 PROGRESS_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_int64)
@@ -68,6 +69,13 @@ def lib():
     L.ptx_render_raw_device.argtypes = [C.c_void_p, C.POINTER(abi.RenderParams), C.c_void_p, C.c_void_p,
                                         C.POINTER(abi.Stats)]
     L.ptx_film_resolve_device.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.ptx_film_resolve_banded_device.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_int32,
+                                                 C.c_int32, C.c_void_p, C.c_void_p]
+    L.ptx_render_multi.argtypes = [C.POINTER(C.c_void_p), C.c_int32, C.POINTER(abi.RenderParams), dp, C.POINTER(abi.Stats),
+                                   C.c_void_p, C.c_void_p]
+    L.ptx_scene_replicate.restype = C.c_void_p
+    L.ptx_scene_replicate.argtypes = [C.c_void_p, C.c_int32]
+    L.ptx_release_workspaces.restype = None
     L.ptx_trace_samples.argtypes = [C.c_void_p, C.POINTER(abi.RenderParams), C.c_int64, ip, ip, ip, dp,
                                     C.POINTER(abi.Stats)]
     L.ptx_intersect_rays.argtypes = [C.c_void_p, C.c_int64, dp, dp, dp, ip, C.POINTER(abi.Stats)]
@@ -98,8 +106,9 @@ def _ip(a):
 
 
 def render_params(width, height, samples_per_pixel=1, max_bounces=8, band_rows=32, band_first=0, band_step=0,
-                  count_work=False, time_kernels=False, passes_per_batch=0):
+                  count_work=False, time_kernels=False, passes_per_batch=0, n_gpus=0):
     p = abi.RenderParams()
+    p.n_gpus = n_gpus
     p.width, p.height, p.samples_per_pixel, p.max_bounces = width, height, samples_per_pixel, max_bounces
     p.band_rows, p.band_first, p.band_step = band_rows, band_first, band_step
     p.count_work, p.time_kernels, p.passes_per_batch = int(count_work), int(time_kernels), passes_per_batch
@@ -129,6 +138,19 @@ class Scene:
         self._h = lib().ptx_scene_create(ptr, device)
         if not self._h:
             raise PtxError(f"ptx_scene_create failed: {last_error()}")
+
+    @classmethod
+    def _adopt(cls, handle, device, keepalive=None):
+        s = cls.__new__(cls)
+        s._keep, s.device, s._h = keepalive, device, handle
+        return s
+
+    def replicate(self, device):
+        """ptx_scene_replicate: the same flattened scene uploaded to another device (no second BVH build)."""
+        h = lib().ptx_scene_replicate(self._h, device)
+        if not h:
+            raise PtxError(f"ptx_scene_replicate failed: {last_error()}")
+        return Scene._adopt(h, device, keepalive=self)
 
     def stats(self):
         st = abi.Stats()
@@ -199,6 +221,25 @@ class Scene:
             self.close()
         except Exception:
             pass
+
+
+def render_multi(scenes, width, height, samples_per_pixel, max_bounces, progress=None, **kw):
+    """ptx_render_multi: one image over several scene replicas (one per GPU) inside this process."""
+    p = render_params(width, height, samples_per_pixel, max_bounces, **kw)
+    out = np.zeros((height, width, 3))
+    st = abi.Stats()
+    arr = (C.c_void_p * len(scenes))(*[s._h for s in scenes])
+    cb = PROGRESS_FN(lambda user, n: progress(n)) if progress else None
+    _check(lib().ptx_render_multi(arr, len(scenes), C.byref(p), _dp(out), C.byref(st),
+                                  C.cast(cb, C.c_void_p) if cb else None, None))
+    return out, stats_dict(st)
+
+
+def film_resolve_banded_device(device, width, height, samples_per_pixel, d_gathered_ptr, n_ranks, band_rows, pad_rows,
+                               d_rgb_ptr, stream=None):
+    _check(lib().ptx_film_resolve_banded_device(device, width, height, samples_per_pixel, C.c_void_p(d_gathered_ptr),
+                                                n_ranks, band_rows, pad_rows, C.c_void_p(d_rgb_ptr),
+                                                C.c_void_p(stream) if stream else None))
 
 
 def film_resolve_device(device, width, height, samples_per_pixel, d_raw_ptr, d_rgb_ptr, stream=None):

@@ -55,7 +55,7 @@ class RenderParams(C.Structure):
         ("width", C.c_int32), ("height", C.c_int32), ("samples_per_pixel", C.c_int32), ("max_bounces", C.c_int32),
         ("band_rows", C.c_int32), ("band_first", C.c_int32), ("band_step", C.c_int32),
         ("count_work", C.c_int32), ("time_kernels", C.c_int32), ("passes_per_batch", C.c_int32),
-        ("reserved", C.c_int32 * 2),
+        ("n_gpus", C.c_int32), ("reserved", C.c_int32),
     ]
 
 

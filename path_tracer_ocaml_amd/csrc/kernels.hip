@@ -584,14 +584,14 @@ __device__ __forceinline__ PtTraceResult pt_trace_ray(const PtSceneDev& sc, cons
 #ifndef PT_PRIMARY_PACKET
 #define PT_PRIMARY_PACKET 1
 #endif
-template <int MODE, bool COUNT, bool SWZ>
+template <int MODE, bool COUNT, bool ORIGIN_ZERO, bool SWZ>
 __device__ __forceinline__ PtTraceResult pt_trace_packet(const PtSceneDev& sc, const PtSceneView& sv, uint32_t* wstack,
-                                                         bool valid, V3 d, unsigned long long& c_nodes,
+                                                         bool valid, V3 o, V3 d, unsigned long long& c_nodes,
                                                          unsigned long long& c_prims, unsigned long long& c_floor) {
   const int lane = pt_lane();
-  PtTraverser<MODE, COUNT, true, uint32_t, SWZ> tr;
+  PtTraverser<MODE, COUNT, ORIGIN_ZERO, uint32_t, SWZ> tr;
   unsigned long long no_count = 0; /* lanes without a sample run begin() on a dummy ray: keep them out of the counters */
-  tr.begin(sc, sv, v3(0.0, 0.0, 0.0), valid ? d : v3(0.0, 0.0, -1.0), valid ? c_floor : no_count);
+  tr.begin(sc, sv, valid ? o : v3(0.0, 0.0, 0.0), valid ? d : v3(0.0, 0.0, -1.0), valid ? c_floor : no_count);
   unsigned long long remaining = __ballot(valid && tr.walking);
   while (remaining != 0) {
     /* the lanes that share the first remaining lane's direction signs */
@@ -633,7 +633,9 @@ __device__ __forceinline__ PtTraceResult pt_trace_packet(const PtSceneDev& sc, c
             const double t_min = 0.0;
             for (uint32_t k = 0; k < n_real; ++k) {
               const double* sp4 = sv.sph + (size_t)(ua + k) * 4;
-              const double fx = sp4[0], fy = sp4[1], fz = sp4[2]; /* f = center - origin, origin = (+0, +0, +0) */
+              /* f = center - origin; for camera rays the origin is (+0, +0, +0) and x - (+0) == x bit for bit */
+              const double fx = ORIGIN_ZERO ? sp4[0] : sp4[0] - tr.o.x, fy = ORIGIN_ZERO ? sp4[1] : sp4[1] - tr.o.y,
+                           fz = ORIGIN_ZERO ? sp4[2] : sp4[2] - tr.o.z;
               const double r2 = sp4[3] * sp4[3];
               const double bp = pt_fma(fx, tr.d.x, pt_fma(fy, tr.d.y, fz * tr.d.z));
               const double bp_over_a = bp * tr.one_over_a;
@@ -771,7 +773,7 @@ __device__ __forceinline__ PtSceneView pt_scene_view(const PtSceneDev& sc, unsig
 #ifndef PT_TRACE_BLOCK_GLOBAL
 #define PT_TRACE_BLOCK_GLOBAL 256 /* workgroup size when the scene is traversed from HBM/L2 (512: -6 % on ganesha-like) */
 #endif
-template <int MODE, bool COUNT, bool PRIMARY, bool LDS_SCENE>
+template <int MODE, bool COUNT, bool PRIMARY, bool LDS_SCENE, bool PACKET>
 /* Simd_leaf + LDS scene fits 64 VGPRs without spilling: ask for 2 x 1024-thread workgroups per CU.  The Array_leaf
  * variants (triangle / scalar-sphere code) need ~100 VGPRs: forcing 64 would spill to scratch (1.5 GB of HBM
  * writes per launch on cornell). */
@@ -791,20 +793,25 @@ __global__ __launch_bounds__(PT_TRACE_BLOCK_OF(MODE, LDS_SCENE), (LDS_SCENE && M
   const uint32_t nwaves = gridDim.x * waves_per_block;
   unsigned long long c_nodes = 0, c_prims = 0, c_floor = 0, c_seg = 0;
 
-  if (PRIMARY && PT_PRIMARY_PACKET && LDS_SCENE) { /* from HBM/L2 one shared node fetch per step serialises the latency: -3 % */
+  if (PACKET) { /* the 64 rays of the wave walk the tree together (pt_trace_packet) */
     /* the wave's private stack area (stack_depth x 64 entries) holds the shared (node, mask) stack: 12 B per level */
     uint32_t* wstack = (uint32_t*)((StackT*)lds_raw + (size_t)wave_in_block * stack_depth * PT_WAVE);
     for (uint32_t chunk = gwave; (unsigned long long)chunk * PT_WAVE < n; chunk += nwaves) {
       const uint32_t i = chunk * PT_WAVE + lane;
       bool valid = i < n;
-      V3 d = v3(0.0, 0.0, -1.0);
+      V3 o = v3(0.0, 0.0, 0.0), d = v3(0.0, 0.0, -1.0);
       if (valid) {
-        const PtPrimarySample ps = pt_primary_decode(g, i);
-        valid = ps.valid;
-        if (valid) d = pt_primary_dir(sc, g, ps, alpha);
+        if (PRIMARY) {
+          const PtPrimarySample ps = pt_primary_decode(g, i);
+          valid = ps.valid;
+          if (valid) d = pt_primary_dir(sc, g, ps, alpha);
+        } else {
+          o = v3(q.ox[i], q.oy[i], q.oz[i]);
+          d = v3(q.dx[i], q.dy[i], q.dz[i]);
+        }
       }
       if (COUNT && valid) c_seg++;
-      const PtTraceResult r = pt_trace_packet<MODE, COUNT, LDS_SCENE>(sc, sv, wstack, valid, d, c_nodes, c_prims, c_floor);
+      const PtTraceResult r = pt_trace_packet<MODE, COUNT, PRIMARY, LDS_SCENE>(sc, sv, wstack, valid, o, d, c_nodes, c_prims, c_floor);
       if (valid) {
         hits.t[i] = r.t;
         hits.slot[i] = r.slot;
@@ -1427,21 +1434,37 @@ __global__ __launch_bounds__(256) void k_accum(PtContrib contrib, long long npix
 struct PtFilm3 {
   double w[9];
 };
+/* Where image row y lives in the raw-sum buffer the film reads.  world <= 1: row y of a (height x width) image.
+ * world > 1: the buffer is the GATHERED multi-rank layout [rank][pad_rows][width][3] -- rank r's compact rows exactly
+ * as ptx_render_raw_device left them (interleaved bands r, r + world, ... of band_rows rows) -- so the film reads the
+ * bands in place and rank 0 never un-permutes them. */
+struct PtBandMap {
+  int world, band_rows, pad_rows;
+};
+__device__ __forceinline__ long long pt_band_row(const PtBandMap& m, int y) {
+  if (m.world <= 1) return y;
+  const int band = y / m.band_rows;
+  const int rank = band % m.world;
+  const int local = (band / m.world) * m.band_rows + (y - band * m.band_rows);
+  return (long long)rank * m.pad_rows + local;
+}
 /* Film_tile.write_pixel splats sample s at its own pixel q to q + (dx, dy) with weight k[dy][dx]
  * (film_tile.ml:23-45); stitch_tile drops what falls outside the image (integrator.ml:114-128).  As a
  * gather: P = sum_taps k[dy][dx] * S(P - (dx, dy)) over in-image neighbours, then sqrt(v * (1/spp)). */
 __global__ __launch_bounds__(256) void k_film(const double* __restrict__ raw, int width, int height, double spp_inv,
-                                              PtFilm3 kern, double* __restrict__ out) {
+                                              PtFilm3 kern, PtBandMap map, double* __restrict__ out) {
   const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= (long long)width * height) return;
   const int x = (int)(p % width), y = (int)(p / width);
   double r = 0.0, g = 0.0, b = 0.0;
   int k = 0;
   for (int dy = -1; dy <= 1; ++dy) {
+    const int sy = y - dy;
+    const long long srow = (sy >= 0 && sy < height) ? pt_band_row(map, sy) : 0;
     for (int dx = -1; dx <= 1; ++dx, ++k) {
-      const int sx = x - dx, sy = y - dy;
+      const int sx = x - dx;
       if (sx < 0 || sx >= width || sy < 0 || sy >= height) continue;
-      const double* s = raw + ((long long)sy * width + sx) * 3;
+      const double* s = raw + (srow * width + sx) * 3;
       const double wgt = kern.w[k];
       r = pt_fma(wgt, s[0], r);
       g = pt_fma(wgt, s[1], g);

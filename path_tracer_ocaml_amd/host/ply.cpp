@@ -112,7 +112,16 @@ extern "C" {
 
 const char* pth_last_error(void) { return g_err.c_str(); }
 
+static pth_ply* ply_load_impl(const char* path);
 pth_ply* pth_ply_load(const char* path) {
+  try {
+    return ply_load_impl(path);
+  } catch (const std::exception& e) { // bad_alloc / length_error on a hostile header: report, never terminate the host
+    g_err = std::string("PLY load failed: ") + e.what();
+    return nullptr;
+  }
+}
+static pth_ply* ply_load_impl(const char* path) {
   std::ifstream f(path, std::ios::binary);
   if (!f) {
     g_err = std::string("cannot open ") + path;
@@ -179,7 +188,24 @@ pth_ply* pth_ply_load(const char* path) {
       }
       Element e;
       e.name = w[1];
-      e.count = std::atoll(w[2].c_str());
+      // Int.of_string (ply.ml:278) raises on anything that is not an integer literal; a negative count then
+      // fails in Array.create.  Both are refused here (digits and '_' separators only, as Base accepts).
+      {
+        const std::string& c = w[2];
+        size_t k = (!c.empty() && c[0] == '+') ? 1 : 0;
+        bool ok = k < c.size() && c[k] != '_';
+        long long v = 0;
+        for (; ok && k < c.size(); ++k) {
+          if (c[k] == '_') continue;
+          if (c[k] < '0' || c[k] > '9' || v > (1ll << 52)) ok = false;
+          else v = v * 10 + (c[k] - '0');
+        }
+        if (!ok) {
+          g_err = "Int.of_string: " + c + " (element count must be a non-negative integer)";
+          return nullptr;
+        }
+        e.count = v;
+      }
       elements.push_back(e);
     } else {
       if (elements.empty()) {
@@ -222,6 +248,7 @@ pth_ply* pth_ply_load(const char* path) {
       if (is_float(p.length_type) || is_float(p.type)) return fail("expected integer type in list property " + p.name);
       if (ply->rows.count(p.name) || ply->counts.count(p.name)) return fail("duplicate key " + p.name); // Map.of_alist_exn
       if (ei + 1 != elements.size()) return fail("a list element must be the last element (the reference's list reader does not advance its input, ply.ml:219-235)");
+      if ((size_t)e.count > (buf.size() - pos) / (type_size(p.length_type) ? type_size(p.length_type) : 1)) return fail("truncated list element " + e.name);
       std::vector<std::vector<int32_t>> rows((size_t)e.count);
       const size_t ls = type_size(p.length_type), es = type_size(p.type);
       for (long long i = 0; i < e.count; ++i) {
@@ -239,7 +266,8 @@ pth_ply* pth_ply_load(const char* path) {
       if (ply->counts.count(e.name)) return fail("duplicate key " + e.name);
       size_t width = 0;
       for (const Property& p : e.props) width += type_size(p.type);
-      if (pos + width * (size_t)e.count > buf.size()) return fail("truncated element " + e.name);
+      if (width > 0 && (size_t)e.count > (buf.size() - pos) / width) return fail("truncated element " + e.name);
+      if (width == 0 && e.count > (1ll << 28)) return fail("element " + e.name + " has no properties and an absurd count");
       size_t off = 0;
       for (const Property& p : e.props) {
         if (is_float(p.type)) {

@@ -5,7 +5,8 @@
 //   -o, --output=PATH (default output.png)         --no-progress
 //   --max-ray-bounces=INT (default 8)
 // plus shirley_spheres' own --no-simd (shirley_spheres/bin/main.ml:12-23), and the prints of
-// shirley_spheres/bin/main.ml:254-267 / render_command.ml:108.  Additions: --scene, --device.
+// shirley_spheres/bin/main.ml:254-267 / render_command.ml:108.  Additions: --scene, --device, --gpus (SURVEY section 5
+// "config / flags": the image spread over N GPUs of the node inside this process, ptx_render_params.n_gpus).
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -27,6 +28,7 @@ struct Args {
   bool no_simd = false;
   std::string scene = "shirley";
   int device = 0;
+  int gpus = 1;
   int ganesha_triangles = 150000;
   double ceiling_emit = 12.0;
   std::string ganesha_ply; // -ganesha-ply <file> (ganesha/bin/main.ml:19-24); empty = synthetic stand-in mesh
@@ -36,7 +38,7 @@ struct Args {
   if (msg) std::fprintf(stderr, "%s: %s\n", prog, msg);
   std::fprintf(stderr,
                "Usage: %s -d WIDTH,HEIGHT [--samples-per-pixel=INT] [-o PATH] [--no-progress]\n"
-               "          [--max-ray-bounces=INT] [--no-simd] [--scene=shirley|cornell|ganesha] [--device=INT]\n"
+               "          [--max-ray-bounces=INT] [--no-simd] [--scene=shirley|cornell|ganesha] [--device=INT] [--gpus=INT]\n"
                "          [--ganesha-ply=PATH] [--triangles=INT] [--ceiling-emit=FLOAT]\n",
                prog);
   std::exit(msg ? 124 : 0); // Cmdliner exits 124 on a CLI error
@@ -74,6 +76,7 @@ Args parse(int argc, char** argv) {
     else if (take_value(argc, argv, i, "max-ray-bounces", nullptr, &v)) a.max_bounces = std::atoi(v.c_str());
     else if (take_value(argc, argv, i, "scene", nullptr, &v)) a.scene = v;
     else if (take_value(argc, argv, i, "device", nullptr, &v)) a.device = std::atoi(v.c_str());
+    else if (take_value(argc, argv, i, "gpus", nullptr, &v)) a.gpus = std::atoi(v.c_str());
     else if (take_value(argc, argv, i, "triangles", nullptr, &v)) a.ganesha_triangles = std::atoi(v.c_str());
     else if (take_value(argc, argv, i, "ceiling-emit", nullptr, &v)) a.ceiling_emit = std::atof(v.c_str());
     else if (take_value(argc, argv, i, "ganesha-ply", nullptr, &v)) a.ganesha_ply = v;
@@ -84,6 +87,12 @@ Args parse(int argc, char** argv) {
     else usage(argv[0], (std::string("unknown option ") + argv[i]).c_str());
   }
   if (!have_dim) usage(argv[0], "required option --dimension is missing");
+  // checked here, before anything is allocated from them (Cmdliner would also refuse a malformed WIDTH,HEIGHT)
+  if (a.width <= 0 || a.height <= 0) usage(argv[0], "invalid value for --dimension, WIDTH and HEIGHT must be positive");
+  if ((long long)a.width * a.height > (1ll << 31)) usage(argv[0], "invalid value for --dimension, image too large");
+  if (a.samples_per_pixel < 1) usage(argv[0], "invalid value for --samples-per-pixel, must be >= 1");
+  if (a.max_bounces < 0) usage(argv[0], "invalid value for --max-ray-bounces, must be >= 0");
+  if (a.gpus < 1) usage(argv[0], "invalid value for --gpus, must be >= 1");
   return a;
 }
 
@@ -116,14 +125,13 @@ int main(int argc, char** argv) {
   pth_scene* hs = nullptr;
   if (a.scene == "shirley") hs = pth_scene_shirley(a.width, a.height, a.no_simd ? 1 : 0, 42); // Random.init 42
   else if (a.scene == "cornell") hs = pth_scene_cornell(a.width, a.height, a.ceiling_emit);
-  else if (a.scene == "ganesha") {
+  else if (a.scene == "ganesha")
     hs = a.ganesha_ply.empty() ? pth_scene_ganesha_like(a.width, a.height, a.ganesha_triangles, 7) : pth_scene_ganesha_ply(a.ganesha_ply.c_str(), a.width, a.height);
-    if (!hs) {
-      std::fprintf(stderr, "%s\n", pth_last_error());
-      return 1;
-    }
-  }
   else usage(argv[0], "unknown --scene");
+  if (!hs) {
+    std::fprintf(stderr, "%s: cannot build scene %s: %s\n", argv[0], a.scene.c_str(), pth_last_error());
+    return 1;
+  }
   const ptx_scene_desc* d = pth_scene_desc(hs);
   std::printf("dim = %d x %d;\n", a.width, a.height);
   if (d->n_spheres) std::printf("#spheres = %d\n", d->n_spheres);
@@ -155,6 +163,7 @@ int main(int argc, char** argv) {
   ptx_render_params p;
   std::memset(&p, 0, sizeof p);
   p.width = a.width; p.height = a.height; p.samples_per_pixel = a.samples_per_pixel; p.max_bounces = a.max_bounces;
+  p.n_gpus = a.gpus;
   std::vector<double> rgb((size_t)a.width * a.height * 3);
   Progress prog;
   prog.total = (long long)a.width * a.height;

@@ -151,3 +151,46 @@ def test_config5_shirley_4k_rows_of_one_rank_of_eight(P, oracle):
     got = part.cpu().numpy()[lr, px]
     assert np.array_equal(sums.view(np.uint64), got.view(np.uint64))
     scene.close()
+
+
+def test_config5_shirley_4k_all_eight_band_shares(P, oracle):
+    """BASELINE configs[4] in full: all 8 ranks' shares of 3840x2160 spp=256 rendered one after the other on this GPU
+    into the gathered [rank][pad_rows][W][3] layout exactly as bench.py --gpus 8 fills it (8-row bands), resolved by
+    the banded film kernel, and compared bit for bit with the one-rank render of the whole frame; sampled pixels
+    against the oracle.  Only the transport (RCCL sends) is not exercised here."""
+    torch = pytest.importorskip("torch")
+    from path_tracer_ocaml_amd import host as H
+    from path_tracer_ocaml_amd import distributed as D
+    w, h, spp, depth, world = 3840, 2160, 256, 8, 8
+    hs = H.shirley_spheres(w, h)
+    scene = P.Scene(hs.ptr, 0, keepalive=hs)
+    pad = D.max_local_rows(h, world)
+    gathered = torch.zeros((world, pad, w, 3), dtype=torch.float64, device="cuda:0")
+    samples = 0
+    for rank in range(world):
+        params = P.render_params(w, h, spp, depth, band_rows=D.BAND_ROWS, band_first=rank, band_step=world)
+        assert P.local_rows(params) <= pad
+        samples += scene.render_raw_device(params, gathered[rank].data_ptr())["samples"]
+    assert samples == w * h * spp
+    rgb8 = torch.zeros((h, w, 3), dtype=torch.float64, device="cuda:0")
+    P.film_resolve_banded_device(0, w, h, spp, gathered.data_ptr(), world, D.BAND_ROWS, pad, rgb8.data_ptr())
+    whole, _, _ = _raw(P, torch, scene, w, h, spp, depth)
+    rgb1 = torch.zeros_like(rgb8)
+    P.film_resolve_device(0, w, h, spp, whole.data_ptr(), rgb1.data_ptr())
+    idx = torch.as_tensor(D.band_row_index(np.arange(h), world, D.BAND_ROWS, pad), device="cuda:0")
+    assert torch.equal(gathered.view(world * pad, w, 3)[idx].view(torch.int64), whole.view(torch.int64)), "raw sums of the 8 shares != one-rank frame"
+    assert torch.equal(rgb8.view(torch.int64), rgb1.view(torch.int64)), "banded film != film of the whole frame"
+    assert bool(torch.isfinite(rgb8).all()) and float(rgb8.max()) > 0.5
+    rng = np.random.default_rng(9)
+    npx = 48
+    px, py = rng.integers(0, w, npx), rng.integers(0, h, npx)
+    xs, ys, ps = np.repeat(px, spp), np.repeat(py, spp), np.tile(np.arange(spp), npx)
+    od = oracle.desc_shirley(w, h)
+    o_rgb, _ = oracle.Scene(od.ptr, od).trace_samples(w, h, spp, depth, xs, ys, ps)
+    per = o_rgb.reshape(npx, spp, 3)
+    sums = np.zeros((npx, 3))
+    for k in range(spp):
+        sums = sums + per[:, k, :]
+    got = whole.cpu().numpy()[py, px]
+    assert np.array_equal(sums.view(np.uint64), got.view(np.uint64))
+    scene.close()
