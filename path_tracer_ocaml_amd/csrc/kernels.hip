@@ -752,6 +752,80 @@ __device__ __forceinline__ PtSceneView pt_scene_view(const PtSceneDev& sc, unsig
   return sv;
 }
 
+/* Dynamic hand-out of a launch's work units (64-ray chunks for trace, workgroup windows for shade).  A static
+ * stride (unit = wave + k * n_waves) gave every wave ~28 units per launch whose costs differ several-fold (sky
+ * against ground rows, 1 against 8 live bounces): the slowest wave ran ~1.7x the mean and a resident wave was alive
+ * for only 62 % (trace) / 47 % (shade) of its kernel's duration (rocprofv3 SQ_WAVE_CYCLES against the kernel time,
+ * profiles/r02a_sq.json).  Units are dealt from up to 8 counters (workgroups b and b + 8 share an XCD, so a counter's
+ * line stays in one L2: MI355X_MICROARCH.md "dequeue": one word saturates at ~88 atomics / us, 8 sharded heads do
+ * not), PT_CHUNK_FETCH units per atomic.  The counters must be zero at launch.  Wave-uniform. */
+#ifndef PT_CHUNK_FETCH
+#define PT_CHUNK_FETCH 2
+#endif
+#ifndef PT_DYNAMIC_CHUNKS
+#define PT_DYNAMIC_CHUNKS 2
+#endif
+#ifndef PT_DYNAMIC_WINDOWS
+#define PT_DYNAMIC_WINDOWS 1
+#endif
+/* PT_DYNAMIC_CHUNKS: 0 = static stride per wave; 1 = global counters (above); 2 = the workgroup keeps its static
+ * share (chunks blockIdx, blockIdx + gridDim, ...) and its waves take them from a counter in LDS: no global atomic,
+ * and a workgroup's total is the sum of ~450 chunk costs instead of a wave's ~28, so the spread between workgroups is
+ * a quarter of the spread between waves. */
+struct PtChunkFeed {
+  uint32_t* ctr;
+  uint32_t nc, c, limit, next, end;
+  __device__ __forceinline__ void init(uint32_t* work, uint32_t total_units, uint32_t* lds_ctr) {
+#if PT_DYNAMIC_CHUNKS == 0
+    /* static stride: unit = wave + k * n_waves */
+    nc = gridDim.x * (blockDim.x >> 6);
+    c = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    limit = c < total_units ? (total_units - c + nc - 1u) / nc : 0u;
+    next = 0u;
+    end = limit;
+    ctr = work;
+#elif PT_DYNAMIC_CHUNKS == 2
+    nc = gridDim.x;
+    c = blockIdx.x;
+    limit = c < total_units ? (total_units - c + nc - 1u) / nc : 0u;
+    next = end = 0u;
+    ctr = lds_ctr; /* zeroed by the caller before a workgroup barrier */
+#else
+    nc = gridDim.x < 8u ? gridDim.x : 8u;
+    c = blockIdx.x % nc;
+    ctr = work + c;
+    limit = c < total_units ? (total_units - c + nc - 1u) / nc : 0u; /* units c, c + nc, c + 2 nc, ... */
+    next = end = 0u;
+#endif
+  }
+  __device__ __forceinline__ bool take(uint32_t& unit) {
+#if PT_DYNAMIC_CHUNKS == 0
+    if (next >= end) return false;
+#else
+    if (next >= end) {
+      uint32_t k = 0u;
+#if PT_DYNAMIC_CHUNKS == 2
+      if (pt_lane() == 0) k = __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      const uint32_t got = 1u;
+#else
+      if (pt_lane() == 0) k = atomicAdd(ctr, (uint32_t)PT_CHUNK_FETCH);
+      const uint32_t got = PT_CHUNK_FETCH;
+#endif
+      k = (uint32_t)__builtin_amdgcn_readfirstlane((int)k);
+      if (k >= limit) {
+        next = end = limit;
+        return false;
+      }
+      next = k;
+      end = (k + got < limit) ? k + got : limit;
+    }
+#endif
+    unit = next * nc + c;
+    ++next;
+    return true;
+  }
+};
+
 /* The traverse + intersect stage.  PRIMARY: bounce 0, rays come from the sampler + camera, not from a queue.
  * LDS_SCENE: the whole tree and every leaf packet are first copied into LDS (small scenes: Shirley is
  * 22 KB of nodes + 22 KB of packets), so node / packet reads are ds_read_b128 instead of L1 traffic.
@@ -779,24 +853,27 @@ template <int MODE, bool COUNT, bool PRIMARY, bool LDS_SCENE, bool PACKET>
  * writes per launch on cornell). */
 __global__ __launch_bounds__(PT_TRACE_BLOCK_OF(MODE, LDS_SCENE), (LDS_SCENE && MODE == PT_MODE_SIMD) ? PT_TRACE_LDS_WAVES : PT_TRACE_GLOBAL_WAVES) void k_trace(PtSceneDev sc, PtQueue q, PtHits hits, int stack_depth,
                                                PtCounters* counters, PtGenParams g, const double* __restrict__ alpha,
-                                               uint32_t n_primary) {
+                                               uint32_t n_primary, uint32_t* work) {
   extern __shared__ __attribute__((aligned(64))) unsigned char lds_raw[];
   const int lane = pt_lane();
   const int wave_in_block = (int)(threadIdx.x >> 6);
-  const uint32_t waves_per_block = blockDim.x >> 6;
   /* LDS-resident scenes have < 65536 nodes: 16-bit stack entries halve the stack footprint */
   typedef typename std::conditional<LDS_SCENE, uint16_t, uint32_t>::type StackT;
   StackT* stack = (StackT*)lds_raw + (size_t)wave_in_block * stack_depth * PT_WAVE + lane;
+  __shared__ uint32_t lds_chunk_ctr;
+  if (threadIdx.x == 0) lds_chunk_ctr = 0u;
   const PtSceneView sv = pt_scene_view<MODE, LDS_SCENE, StackT>(sc, lds_raw, stack_depth);
+  if (!LDS_SCENE) __syncthreads(); /* pt_scene_view ends with a barrier only when it copies the scene */
   const uint32_t n = PRIMARY ? n_primary : *q.count;
-  const uint32_t gwave = blockIdx.x * waves_per_block + wave_in_block;
-  const uint32_t nwaves = gridDim.x * waves_per_block;
+  PtChunkFeed feed;
+  feed.init(work, (uint32_t)(((unsigned long long)n + PT_WAVE - 1) / PT_WAVE), &lds_chunk_ctr);
+  uint32_t chunk;
   unsigned long long c_nodes = 0, c_prims = 0, c_floor = 0, c_seg = 0;
 
   if (PACKET) { /* the 64 rays of the wave walk the tree together (pt_trace_packet) */
     /* the wave's private stack area (stack_depth x 64 entries) holds the shared (node, mask) stack: 12 B per level */
     uint32_t* wstack = (uint32_t*)((StackT*)lds_raw + (size_t)wave_in_block * stack_depth * PT_WAVE);
-    for (uint32_t chunk = gwave; (unsigned long long)chunk * PT_WAVE < n; chunk += nwaves) {
+    while (feed.take(chunk)) {
       const uint32_t i = chunk * PT_WAVE + lane;
       bool valid = i < n;
       V3 o = v3(0.0, 0.0, 0.0), d = v3(0.0, 0.0, -1.0);
@@ -822,36 +899,39 @@ __global__ __launch_bounds__(PT_TRACE_BLOCK_OF(MODE, LDS_SCENE), (LDS_SCENE && M
       }
     }
   } else
-  for (uint32_t chunk = gwave; (unsigned long long)chunk * PT_WAVE < n; chunk += nwaves) {
+  while (feed.take(chunk)) { /* no `continue` below: every lane comes back to take() together (it is wave-uniform) */
     const uint32_t i = chunk * PT_WAVE + lane;
-    if (i >= n) continue;
-    V3 o, d;
-    if (PRIMARY) {
-      const PtPrimarySample ps = pt_primary_decode(g, i);
-      if (!ps.valid) continue;
-      o = v3(0.0, 0.0, 0.0); /* P3.origin */
-      d = pt_primary_dir(sc, g, ps, alpha);
-    } else {
-      o = v3(q.ox[i], q.oy[i], q.oz[i]);
-      d = v3(q.dx[i], q.dy[i], q.dz[i]);
-    }
-    if (COUNT) c_seg++;
-    const unsigned long long diag_n0 = c_nodes;
-    const PtTraceResult r = pt_trace_ray<MODE, COUNT, PRIMARY, StackT, LDS_SCENE>(sc, sv, stack, o, d, c_nodes, c_prims, c_floor);
-    if (COUNT && PT_DIAG == 2 && !PRIMARY) {
-      unsigned long long m = c_nodes - diag_n0;
-      for (int off = 32; off > 0; off >>= 1) {
-        const unsigned long long other = __shfl_xor(m, off);
-        m = other > m ? other : m;
+    bool valid = i < n;
+    V3 o = v3(0.0, 0.0, 0.0), d = v3(0.0, 0.0, -1.0); /* P3.origin */
+    if (valid) {
+      if (PRIMARY) {
+        const PtPrimarySample ps = pt_primary_decode(g, i);
+        valid = ps.valid;
+        if (valid) d = pt_primary_dir(sc, g, ps, alpha);
+      } else {
+        o = v3(q.ox[i], q.oy[i], q.oz[i]);
+        d = v3(q.dx[i], q.dy[i], q.dz[i]);
       }
-      PT_DIAG_WAVE_SLOTS(c_floor);
-      if (lane == 0) c_floor += m * 64 - 64;
     }
-    hits.t[i] = r.t;
-    hits.slot[i] = r.slot;
-    if (MODE == PT_MODE_ARRAY && sc.has_triangles) {
-      hits.u[i] = r.u;
-      hits.v[i] = r.v;
+    if (valid) {
+      if (COUNT) c_seg++;
+      const unsigned long long diag_n0 = c_nodes;
+      const PtTraceResult r = pt_trace_ray<MODE, COUNT, PRIMARY, StackT, LDS_SCENE>(sc, sv, stack, o, d, c_nodes, c_prims, c_floor);
+      if (COUNT && PT_DIAG == 2 && !PRIMARY) {
+        unsigned long long m = c_nodes - diag_n0;
+        for (int off = 32; off > 0; off >>= 1) {
+          const unsigned long long other = __shfl_xor(m, off);
+          m = other > m ? other : m;
+        }
+        PT_DIAG_WAVE_SLOTS(c_floor);
+        if (lane == 0) c_floor += m * 64 - 64;
+      }
+      hits.t[i] = r.t;
+      hits.slot[i] = r.slot;
+      if (MODE == PT_MODE_ARRAY && sc.has_triangles) {
+        hits.u[i] = r.u;
+        hits.v[i] = r.v;
+      }
     }
   }
   if (COUNT) {
@@ -1263,7 +1343,7 @@ __device__ __forceinline__ uint32_t pt_block_sort_by_category(int key, uint32_t*
 template <bool EMIT, bool PRIMARY>
 __global__ __launch_bounds__(PT_SHADE_BLOCK, PT_SHADE_WAVES) void k_shade(PtSceneDev sc, PtQueue q, PtHits hits, PtQueue out, PtContrib contrib,
                                                 const double* __restrict__ alpha, int bounce, int last_bounce,
-                                                PtGenParams g, uint32_t n_primary) {
+                                                PtGenParams g, uint32_t n_primary, uint32_t* work) {
 #if PT_APPEND_BINS > 1
   __shared__ uint32_t lds_bins[65];
 #else
@@ -1271,22 +1351,52 @@ __global__ __launch_bounds__(PT_SHADE_BLOCK, PT_SHADE_WAVES) void k_shade(PtScen
 #endif
   __shared__ uint32_t lds_cnt[PT_N_CAT * 8];
   __shared__ uint16_t lds_perm[PT_SHADE_BLOCK];
+  __shared__ uint32_t lds_win[2];
   const uint32_t n = PRIMARY ? n_primary : *q.count;
   const double pi = 3.14159265358979323846;
 
-  /* The sort key of an entry is two dependent loads away (hit slot -> its category).  They are issued one
-   * iteration (category) and two iterations (slot) ahead, so the chain hides behind the previous groups' shading. */
-  const uint32_t stride = gridDim.x * blockDim.x;
+  /* Windows of blockDim entries are handed out dynamically (PtChunkFeed's counters, one atomic per window by
+   * thread 0).  The workgroup always knows its next THREE windows (wA now, wB, wC): the sort key of an entry is two
+   * dependent loads away (hit slot -> its category), issued one iteration (category) and two iterations (slot) ahead,
+   * so the chain hides behind the previous windows' shading; and the atomic for the window after those is issued a
+   * whole iteration before its value is broadcast, so nobody waits for it. */
+  const uint32_t nc = gridDim.x < 8u ? gridDim.x : 8u, cc = blockIdx.x % nc;
+  const uint32_t total_win = (uint32_t)(((unsigned long long)n + blockDim.x - 1) / blockDim.x);
+  const uint32_t win_limit = cc < total_win ? (total_win - cc + nc - 1u) / nc : 0u; /* windows cc, cc + nc, ... */
+  uint32_t pending = 0u; /* thread 0: the hand-out counter's value for the window after wC */
+#if PT_DYNAMIC_WINDOWS
+  if (threadIdx.x == 0) {
+    lds_win[0] = atomicAdd(work + cc, 3u);
+    pending = atomicAdd(work + cc, 1u);
+  }
+  __syncthreads();
+  uint32_t wA = lds_win[0], wB = wA + 1u, wC = wA + 2u;
+  __syncthreads();
+#else
+  /* static stride over the windows of this counter's share: workgroup j of the gridDim / nc that share it takes
+   * windows j, j + gridDim / nc, ... (grids are multiples of 8 or smaller than 8) */
+  const uint32_t wg_per_ctr = (gridDim.x + nc - 1u) / nc;
+  uint32_t wA = blockIdx.x / nc, wB = wA + wg_per_ctr, wC = wB + wg_per_ctr;
+#endif
+#define PT_WIN_BASE(w) (((w) < win_limit) ? ((w) * nc + cc) * blockDim.x : 0xffffffffu) /* 0xffffffff: no such window */
   int pf_key = PT_CAT_NONE, pf_slot = -2; /* key of this iteration's entry; slot of the next iteration's (-2: none) */
   if (PT_SHADE_SORT && PT_SHADE_PREFETCH && !PRIMARY) {
-    const uint32_t i0 = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i0 < n) {
-      const int sl = hits.slot[i0];
+    const uint32_t bA = PT_WIN_BASE(wA), bB = PT_WIN_BASE(wB);
+    if (bA != 0xffffffffu && bA + threadIdx.x < n) {
+      const int sl = hits.slot[bA + threadIdx.x];
       pf_key = sl < 0 ? PT_CAT_MISS : (int)sc.slot_cat[sl];
     }
-    if ((unsigned long long)i0 + stride < n) pf_slot = hits.slot[i0 + stride];
+    if (bB != 0xffffffffu && bB + threadIdx.x < n) pf_slot = hits.slot[bB + threadIdx.x];
   }
-  for (uint32_t base_i = blockIdx.x * blockDim.x; base_i < n; base_i += stride) {
+  for (int it = 0; wA < win_limit; ++it) {
+    const uint32_t base_i = PT_WIN_BASE(wA);
+    /* the window after wC: broadcast what thread 0 fetched an iteration ago, fetch the one after it */
+#if PT_DYNAMIC_WINDOWS
+    if (threadIdx.x == 0) {
+      lds_win[it & 1] = pending;
+      pending = atomicAdd(work + cc, 1u);
+    }
+#endif
     uint32_t i = base_i + threadIdx.x;
     if (PT_SHADE_SORT && !PRIMARY) {
       int key = PT_CAT_NONE;
@@ -1294,8 +1404,8 @@ __global__ __launch_bounds__(PT_SHADE_BLOCK, PT_SHADE_WAVES) void k_shade(PtScen
         key = pf_key;
         /* next iteration's key from the slot fetched an iteration ago; the slot after that */
         pf_key = pf_slot == -2 ? PT_CAT_NONE : (pf_slot < 0 ? PT_CAT_MISS : (int)sc.slot_cat[pf_slot]);
-        const unsigned long long i2 = (unsigned long long)i + 2ull * stride;
-        pf_slot = i2 < n ? hits.slot[i2] : -2;
+        const uint32_t bC = PT_WIN_BASE(wC);
+        pf_slot = (bC != 0xffffffffu && bC + threadIdx.x < n) ? hits.slot[bC + threadIdx.x] : -2;
       } else if (i < n) {
         const int sl = hits.slot[i];
         key = sl < 0 ? PT_CAT_MISS : (int)sc.slot_cat[sl];
@@ -1409,7 +1519,17 @@ __global__ __launch_bounds__(PT_SHADE_BLOCK, PT_SHADE_WAVES) void k_shade(PtScen
       out.id[dst] = id;
       out.offset[dst] = offset;
     }
+    /* every path through the append above crossed a workgroup barrier after thread 0's store to lds_win[it & 1],
+     * and the next store to that word is two iterations away */
+    wA = wB;
+    wB = wC;
+#if PT_DYNAMIC_WINDOWS
+    wC = lds_win[it & 1];
+#else
+    wC = wC + wg_per_ctr;
+#endif
   }
+#undef PT_WIN_BASE
 }
 
 /* ------------------------------------------------------------------ accumulate + film */
