@@ -231,17 +231,30 @@ __device__ __forceinline__ bool pt_slab_hit_exact(const double* nb, V3 o, V3 inv
   return pt_slab_hit(n, o, inv, t_min, t_max);
 }
 
-/* LDS image of a node for the sign-selected slab test: per axis the triple (mn, mx, mn), so that the pair
- * starting at +0 is (near, far) for a direction component > 0 and the pair starting at +8 bytes is (near, far) for a
- * component < 0.  min(t0, t1) / max(t0, t1) of Bbox.hit_range are then known WITHOUT computing them: for 1/d > 0,
- * (mn - o)*inv <= (mx - o)*inv because rounding is monotone, and the reverse for 1/d < 0 -- the same two values,
- * six v_min/v_max_f64 fewer per node.  96 bytes: 9 bounds, a, b, n_real, pad. */
-#define PT_SWZ_NODE_BYTES 96
+/* LDS image of a node for LDS-resident scenes: 32 bytes, binary32 -- a FILTER in front of the binary64 slab test.
+ *   words 0..5  mn.x mn.y mn.z mx.x mx.y mx.z rounded to binary32
+ *   word 6      branch: lhs | rhs << 16 (node BYTE offsets into this image);  leaf: first slot | real slot count << 16
+ *   word 7      bits of `mag` = max |bound| of the node (binary32, rounded up), low 2 bits replaced by the axis (3 = leaf)
+ * Bbox.is_hit (bbox.ml:40-56) is a boolean of binary64 quantities; the image decides it in binary32 with a rigorous
+ * error bound and hands the (rare) undecided lanes to the binary64 code, so the boolean -- and with it every hit, every
+ * work counter and every pixel -- is the reference's.  For a ray with |1/d| < 2^100 (else: always binary64):
+ *   t~ = fma32(bound32, inv32, -(o * inv)32) differs from the reference's fl64((bound - o) * inv) by at most
+ *        3.2 * 2^-24 * (|bound| + |o|) * |inv|  <=  M := 3.2 * 2^-24 * (mag + max|o|) * max|inv|
+ *   (three binary32 roundings of the inputs, one of the fma, the reference's own two binary64 roundings);
+ *   max / min are 1-Lipschitz, so lo~ = max(0, a~) and hi~ = min(b~, t32) are within M (+ 2^-24 t for the rounded
+ *   closest-hit distance) of the reference's lo, hi, and u = hi~ - lo~ (one more rounding) within 8.4 * 2^-24 * (..)
+ *   + 2^-24 t of hi - lo.  With m2 = 2^-19 * (mag + max|o|) * max|inv| + 2^-21 * t32  (twice that bound):
+ *        u >= m2  =>  lo <= hi (hit)        u < -m2  =>  lo > hi (miss)        otherwise: binary64.
+ * The undecided share is ~4 m2 / (hi - lo spread) ~ 1e-5 per test, scale-free because mag is the node's own. */
+#define PT_SWZ_NODE_BYTES 32
+#ifndef PT_F32_FILTER_STATS
+#define PT_F32_FILTER_STATS 0 /* diagnostic: count undecided tests in the floor counter */
+#endif
 
 /* where the traversal data of this launch lives: HBM/L2 (large scenes) or an LDS copy (small scenes) */
 struct PtSceneView {
   const PtNode* nodes;
-  const unsigned char* swz_nodes; /* LDS-resident scenes: PT_SWZ_NODE_BYTES per node */
+  const unsigned char* swz_nodes; /* LDS-resident scenes: the binary32 filter image, PT_SWZ_NODE_BYTES per node */
   const double* sph;
   const double* tri;
   const uint8_t* kind;
@@ -262,6 +275,9 @@ struct PtTraceResult {
 #ifndef PT_WALK_MIN
 #define PT_WALK_MIN 8
 #endif
+#ifndef PT_PRED_WALK
+#define PT_PRED_WALK 0 /* 1: the predicated (scalar-lean) walk and scan for LDS-resident Simd_leaf scenes (measured: halves the scalar instructions, +25 % vector instructions, +3x LDS bank conflicts: 5 % slower) */
+#endif
 /* PT_DIAG (diagnostic builds only, tools/diag_utilisation.sh): re-purposes the COUNT counters of SECONDARY launches
  * to measure lane utilisation per traversal phase: nodes = useful lane steps, floor = lane slots the wave spent.
  * 1: node walk   2: node walk if only the per-chunk tail were lost   3: packet scan   4: packet heavy part */
@@ -279,10 +295,14 @@ struct PtTraceResult {
  * ray as soon as enough of the wave has finished). */
 template <int MODE, bool COUNT, bool ORIGIN_ZERO, typename StackT, bool SWZ>
 struct PtTraverser {
-  V3 o, d, inv;
+  V3 o, d, inv; /* SWZ: inv is not kept (the binary64 fallback recomputes 1 / d, the same three divisions) */
   uint32_t dirs;
-  bool exact_slab;
-  uint3 swz_off; /* byte offsets of the (near, far) pair of each axis inside a swizzled LDS node */
+  bool exact_slab; /* SWZ: also set when the binary32 filter does not apply to this ray (|1/d| >= 2^100) */
+  /* binary32 filter constants of the ray (SWZ only): inv32, -(o * inv)32, k2 = 2^-19 max|inv|, c2 = max|o| k2 + 2^-21 t32 */
+  float fix, fiy, fiz, fnx, fny, fnz, k2, c2base, c2, t32;
+#if PT_F32_FILTER_STATS
+  mutable unsigned long long n_undecided = 0, n_wave_fallbacks = 0;
+#endif
   double qa, one_over_a;
   PtTraceResult r;
   int sp;
@@ -304,9 +324,19 @@ struct PtTraverser {
     /* dirs, shape_tree.ml:201 */
     dirs = (d.x >= 0.0 ? 1u : 0u) | (d.y >= 0.0 ? 2u : 0u) | (d.z >= 0.0 ? 4u : 0u);
     exact_slab = !(pt_isfinite(inv.x) && pt_isfinite(inv.y) && pt_isfinite(inv.z));
-    swz_off.x = 0u + (inv.x < 0.0 ? 8u : 0u);
-    swz_off.y = 24u + (inv.y < 0.0 ? 8u : 0u);
-    swz_off.z = 48u + (inv.z < 0.0 ? 8u : 0u);
+    if (SWZ) {
+      const double ax = pt_fabs(inv.x), ay = pt_fabs(inv.y), az = pt_fabs(inv.z);
+      const double imax = __builtin_fmax(ax, __builtin_fmax(ay, az));
+      const double omax = __builtin_fmax(pt_fabs(o.x), __builtin_fmax(pt_fabs(o.y), pt_fabs(o.z)));
+      /* every binary32 intermediate stays far inside the format: (mag + |o|) |inv| < 2^100 * 2^20 */
+      if (!(imax < 0x1p100) || !(omax < 0x1p20)) exact_slab = true;
+      fix = (float)inv.x; fiy = (float)inv.y; fiz = (float)inv.z;
+      fnx = ORIGIN_ZERO ? 0.0f : -(float)(o.x * inv.x);
+      fny = ORIGIN_ZERO ? 0.0f : -(float)(o.y * inv.y);
+      fnz = ORIGIN_ZERO ? 0.0f : -(float)(o.z * inv.z);
+      k2 = (float)imax * 0x1.000002p-19f;
+      c2base = __builtin_fmaf((float)omax * 1.000001f, k2, 1e-30f);
+    }
     r.t = PT_MAX_FINITE;
     r.slot = -1;
     r.u = 0.0;
@@ -339,6 +369,12 @@ struct PtTraverser {
     walking = sc.n_nodes > 0;
     leaf_first = 0;
     leaf_n = 0;
+    if (SWZ) update_t32();
+  }
+  /* the closest hit so far as the filter sees it; called whenever r.t may have changed */
+  __device__ __forceinline__ void update_t32() {
+    t32 = (float)r.t; /* PT_MAX_FINITE -> +inf */
+    c2 = c2base + (t32 < 0x1p120f ? t32 * 0x1p-21f : 0.0f);
   }
 
   /* Visit `node`: bbox test against the closest hit so far, then descend / hold the leaf / pop.  The traversal
@@ -346,31 +382,56 @@ struct PtTraverser {
    * bbox is tested when it is POPPED, against the closest hit so far -- exactly the t_max the reference's recursion
    * passes (shape_tree.ml:210-216). */
   /* Bbox.is_hit of `nd` against the closest hit so far + the node's links (a, b, real slot count) */
-  __device__ __forceinline__ bool test_box(const PtSceneView& sv, uint32_t nd, uint32_t& na, uint32_t& nb, uint32_t& n_real) const {
+  __device__ __forceinline__ bool test_box(const PtSceneView& sv, uint32_t nd, uint32_t& na, uint32_t& nb, uint32_t& n_real, bool active = true) const {
     const double t_min = 0.0;
     bool hit;
     if (SWZ) {
-      const unsigned char* nbase = sv.swz_nodes + (size_t)nd * PT_SWZ_NODE_BYTES;
-      const uint2 links = *(const uint2*)(nbase + 72);
-      na = links.x;
-      nb = links.y;
-      n_real = (nb >> 15) & 0x7fffu; /* meaningful for leaves only (pt_scene_view packs it into the link word) */
-      if (exact_slab) {
-        const double* bx = (const double*)nbase;
-        const double box6[6] = {bx[0], bx[3], bx[6], bx[1], bx[4], bx[7]};
-        hit = pt_slab_hit_exact(box6, o, inv, t_min, r.t);
-      } else {
-        /* (near, far) per axis, selected by the sign of the direction component through the load address;
-         * 8-byte aligned pairs (ds_read2_b64): the +8 variants are not 16-byte aligned */
-        const double* px = (const double*)(nbase + swz_off.x);
-        const double* py = (const double*)(nbase + swz_off.y);
-        const double* pz = (const double*)(nbase + swz_off.z);
-        const double tnx = (ORIGIN_ZERO ? px[0] : px[0] - o.x) * inv.x, tfx = (ORIGIN_ZERO ? px[1] : px[1] - o.x) * inv.x;
-        const double tny = (ORIGIN_ZERO ? py[0] : py[0] - o.y) * inv.y, tfy = (ORIGIN_ZERO ? py[1] : py[1] - o.y) * inv.y;
-        const double tnz = (ORIGIN_ZERO ? pz[0] : pz[0] - o.z) * inv.z, tfz = (ORIGIN_ZERO ? pz[1] : pz[1] - o.z) * inv.z;
-        const double a = __builtin_fmax(tnx, __builtin_fmax(tny, tnz));
-        const double b = __builtin_fmin(tfx, __builtin_fmin(tfy, tfz));
-        hit = __builtin_fmax(t_min, a) <= __builtin_fmin(r.t, b);
+#if defined(PT_DUMMY_VALU) || defined(PT_DUMMY_F64) || defined(PT_DUMMY_SALU)
+      { /* sensitivity experiment (tools/bench_variants.sh): extra instructions of one kind per node test */
+        float xv = fix; double xd = r.t; int xs = (int)nd;
+        (void)xv; (void)xd; (void)xs;
+#ifdef PT_DUMMY_VALU
+#pragma unroll
+        for (int q = 0; q < PT_DUMMY_VALU; ++q) asm volatile("v_add_f32 %0, %0, %0" : "+v"(xv));
+#endif
+#ifdef PT_DUMMY_F64
+#pragma unroll
+        for (int q = 0; q < PT_DUMMY_F64; ++q) asm volatile("v_add_f64 %0, %0, %0" : "+v"(xd));
+#endif
+#ifdef PT_DUMMY_SALU
+        int ss = __builtin_amdgcn_readfirstlane(xs);
+#pragma unroll
+        for (int q = 0; q < PT_DUMMY_SALU; ++q) asm volatile("s_add_u32 %0, %0, 1" : "+s"(ss));
+#endif
+      }
+#endif
+      /* nd is the node's BYTE offset in the binary32 image */
+      const uint4 w0 = *(const uint4*)(sv.swz_nodes + nd), w1 = *(const uint4*)(sv.swz_nodes + nd + 16);
+      na = w1.z & 0xffffu;
+      nb = (w1.z >> 16) | ((w1.w & 3u) << 30);
+      n_real = w1.z >> 16; /* meaningful for leaves only */
+      const float mag = __uint_as_float(w1.w);
+      const float t0x = __builtin_fmaf(__uint_as_float(w0.x), fix, fnx), t1x = __builtin_fmaf(__uint_as_float(w0.w), fix, fnx);
+      const float t0y = __builtin_fmaf(__uint_as_float(w0.y), fiy, fny), t1y = __builtin_fmaf(__uint_as_float(w1.x), fiy, fny);
+      const float t0z = __builtin_fmaf(__uint_as_float(w0.z), fiz, fnz), t1z = __builtin_fmaf(__uint_as_float(w1.y), fiz, fnz);
+      const float a = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(t0x, t1x), __builtin_fminf(t0y, t1y)), __builtin_fminf(t0z, t1z));
+      const float b = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(t0x, t1x), __builtin_fmaxf(t0y, t1y)), __builtin_fmaxf(t0z, t1z));
+      const float u = __builtin_fminf(b, t32) - __builtin_fmaxf(a, 0.0f);
+      const float m2 = __builtin_fmaf(mag, k2, c2);
+      hit = u >= m2;
+      const bool undecided = active && (exact_slab || !(hit || u < -m2));
+      if (__builtin_amdgcn_ballot_w64(undecided) != 0) {
+#if PT_F32_FILTER_STATS
+        if (undecided) n_undecided++;
+        if (pt_lane() == __ffsll((long long)__ballot(1)) - 1) n_wave_fallbacks++;
+#endif
+        if (undecided) { /* the reference's arithmetic, on the binary64 node (global memory: L2-resident, rarely read) */
+          const PtNode* np = sv.nodes + (nd >> 5);
+          const V3 inv64 = v3(1.0 / d.x, 1.0 / d.y, 1.0 / d.z);
+          hit = (!(pt_isfinite(inv64.x) && pt_isfinite(inv64.y) && pt_isfinite(inv64.z)))
+                    ? pt_slab_hit_exact(np->mn, o, inv64, t_min, r.t)
+                    : pt_slab_hit_fast<ORIGIN_ZERO>(np->mn, o, inv64, t_min, r.t);
+        }
       }
     } else {
       const PtNode* np = sv.nodes + nd;
@@ -393,7 +454,8 @@ struct PtTraverser {
       if (axis == PT_NODE_LEAF_AXIS) {
         leaf_first = (int)na;
         leaf_n = (int)n_real; /* real slots; the NaN padding (main.ml:185) can never be selected */
-        if (COUNT && PT_DIAG == 0) c_prims += (unsigned long long)(nb & (SWZ ? 0x7fffu : 0x3fffffffu)); /* Leaf.length incl. padding */
+        /* Leaf.length incl. padding: Simd_leaf pads to a multiple of 4 (main.ml:179-186); the filter image keeps the real count */
+        if (COUNT && PT_DIAG == 0) c_prims += (unsigned long long)(SWZ ? (MODE == PT_MODE_SIMD ? ((n_real + 3u) & ~3u) : n_real) : (nb & 0x3fffffffu));
       } else {
         /* Branch: near child first (shape_tree.ml:209), far child deferred */
         const uint32_t lhs = na, rhs = nb & 0x3fffffffu;
@@ -413,6 +475,93 @@ struct PtTraverser {
         node = PT_STACK_POP(stack, sp);
       }
     }
+  }
+
+  /* The same visit with NO divergent control flow (LDS-resident scenes): every lane executes the whole step and the
+   * lanes that do not `want` one commit nothing.  Why: on this chip a CU has ONE scalar unit for its four SIMDs, and the
+   * exec-mask bookkeeping the compiler emits for nested divergent branches (s_and_saveexec / s_or / s_andn2 per `if`,
+   * loop-exit masks per `break`) made the walk scalar-bound -- ~45 scalar instructions per node test; adding 20 more
+   * slowed the kernel as much as 50 extra binary32 vector instructions did (tools/bench_variants.sh ds20 / dv10).
+   * Here the masks only feed v_cndmask.  The far child is stored above the top of the stack unconditionally (harmless
+   * when the lane does not descend) and the entry a pop would take is read at the top of the step, beside the node.
+   * Returns the lanes that took a leaf.  SWZ only. */
+  __device__ __forceinline__ unsigned long long node_step_pred(const PtSceneView& sv, StackT* stack, bool want,
+                                                               unsigned long long& c_nodes, unsigned long long& c_prims) {
+    /* State lives in integers and is updated with bit masks (0 / ~0 -> v_bfi_b32, v_and, v_or): a `bool` that
+     * survives the loop becomes a lane mask in scalar registers and every update of it costs 2-3 scalar instructions.
+     * walking <=> sp >= 0 here (sp = -1: the ray has run out of nodes). */
+    if (COUNT) c_nodes += want ? 1ull : 0ull;
+    const int32_t wantm = want ? -1 : 0;
+    const int32_t spc = sp > 0 ? sp : 0;
+    const uint32_t popped = PT_STACK_POP(stack, spc > 0 ? spc - 1 : 0);
+    uint32_t na, nb, n_real;
+    const int32_t hitm = (test_box(sv, node, na, nb, n_real, want) ? -1 : 0) & wantm;
+    const uint32_t axis = nb >> 30;
+    const int32_t leafm = ((int32_t)((axis + 1u) << 29)) >> 31; /* axis == 3 <=> bit 2 of axis + 1 */
+    const int32_t takem = hitm & leafm, descm = hitm & ~leafm;
+    const uint32_t lhs = na, rhs = nb & 0x3fffffffu;
+    const int32_t lfm = -(int32_t)((dirs >> axis) & 1u); /* lhs first */
+    const uint32_t nearc = (lhs & (uint32_t)lfm) | (rhs & ~(uint32_t)lfm);
+    const uint32_t farc = (rhs & (uint32_t)lfm) | (lhs & ~(uint32_t)lfm);
+    PT_STACK_PUSH(stack, spc, farc); /* above the top unless `desc` moves the top past it */
+    const int32_t popm = wantm & ~descm;
+    const int32_t morem = ~((sp - 1) >> 31); /* sp > 0 */
+    const int32_t pmm = popm & morem, finm = popm & ~morem;
+    const uint32_t keep = (popped & (uint32_t)pmm) | (node & ~(uint32_t)pmm);
+    node = (nearc & (uint32_t)descm) | (keep & ~(uint32_t)descm);
+    sp = (sp - descm + pmm) | finm;
+    leaf_first = (int)(((uint32_t)na & (uint32_t)takem) | ((uint32_t)leaf_first & ~(uint32_t)takem));
+    leaf_n = (int)((n_real & (uint32_t)takem) | ((uint32_t)leaf_n & ~(uint32_t)takem));
+    if (COUNT) c_prims += takem ? (unsigned long long)(MODE == PT_MODE_SIMD ? ((n_real + 3u) & ~3u) : n_real) : 0ull;
+    return __builtin_amdgcn_ballot_w64(takem != 0);
+  }
+
+  /* Simd_leaf packets for every lane that holds a leaf, with wave-uniform loop bounds (see node_step_pred): the scan
+   * runs k = 0 .. (longest held packet) - 1 for all lanes and a lane beyond its own packet contributes no candidate. */
+  __device__ __forceinline__ void packet_pred(const PtSceneView& sv) {
+    const double t_min = 0.0;
+    const bool held = leaf_n > 0;
+    for (int base = 0;; base += 32) {
+      uint32_t cand = 0;
+      for (int k = 0; k < 32; ++k) {
+        const bool in = base + k < leaf_n;
+        if (__builtin_amdgcn_ballot_w64(in) == 0) break;
+        const double* s = sv.sph + (size_t)(leaf_first + (in ? base + k : 0)) * 4;
+        const double fx = ORIGIN_ZERO ? s[0] : s[0] - o.x, fy = ORIGIN_ZERO ? s[1] : s[1] - o.y,
+                     fz = ORIGIN_ZERO ? s[2] : s[2] - o.z;
+        const double bp_over_a = pt_fma(fx, d.x, pt_fma(fy, d.y, fz * d.z)) * one_over_a;
+        const double wx = pt_fma(d.x, bp_over_a, -fx);
+        const double wy = pt_fma(d.y, bp_over_a, -fy);
+        const double wz = pt_fma(d.z, bp_over_a, -fz);
+        const double disc = (s[3] * s[3]) - pt_fma(wx, wx, pt_fma(wy, wy, wz * wz));
+        cand |= (in && (disc == disc) && !pt_signbit(disc)) ? (1u << k) : 0u;
+      }
+      while (cand != 0) { /* the roots of the candidates, in slot order (lib.rs:169-177: last index wins ties) */
+        const int k = __ffs((int)cand) - 1;
+        cand &= cand - 1u;
+        const double* s = sv.sph + (size_t)(leaf_first + base + k) * 4;
+        const double fx = ORIGIN_ZERO ? s[0] : s[0] - o.x, fy = ORIGIN_ZERO ? s[1] : s[1] - o.y,
+                     fz = ORIGIN_ZERO ? s[2] : s[2] - o.z;
+        const double r2 = s[3] * s[3];
+        const double c = pt_fma(fx, fx, pt_fma(fy, fy, fz * fz)) - r2;
+        const double bp = pt_fma(fx, d.x, pt_fma(fy, d.y, fz * d.z));
+        const double bp_over_a = bp * one_over_a;
+        const double wx = pt_fma(d.x, bp_over_a, -fx);
+        const double wy = pt_fma(d.y, bp_over_a, -fy);
+        const double wz = pt_fma(d.z, bp_over_a, -fz);
+        const double disc = r2 - pt_fma(wx, wx, pt_fma(wy, wy, wz * wz));
+        const double q_rhs = pt_sqrt(qa * disc);
+        const double qq = pt_signbit(bp) ? (bp - q_rhs) : (bp + q_rhs);
+        const double t = pt_signbit(c) ? (qq * one_over_a) : (c / qq);
+        if (!(t < t_min) && t <= r.t) {
+          r.t = t;
+          r.slot = leaf_first + base + k;
+        }
+      }
+      if (__builtin_amdgcn_ballot_w64(base + 32 < leaf_n) == 0) break;
+    }
+    leaf_n = 0;
+    if (held && SWZ) update_t32();
   }
 
   /* Leaf.intersect on the held leaf (caller checks leaf_n > 0) */
@@ -543,6 +692,7 @@ struct PtTraverser {
       }
     }
     leaf_n = 0;
+    if (SWZ) update_t32();
   }
 };
 
@@ -554,10 +704,33 @@ struct PtTraverser {
 template <int MODE, bool COUNT, bool ORIGIN_ZERO, typename StackT, bool SWZ = false>
 __device__ __forceinline__ PtTraceResult pt_trace_ray(const PtSceneDev& sc, const PtSceneView& sv, StackT* stack,
                                                       V3 o, V3 d, unsigned long long& c_nodes,
-                                                      unsigned long long& c_prims, unsigned long long& c_floor) {
+                                                      unsigned long long& c_prims, unsigned long long& c_floor,
+                                                      bool valid = true) {
   PtTraverser<MODE, COUNT, ORIGIN_ZERO, StackT, SWZ> tr;
-  tr.begin(sc, sv, o, d, c_floor);
-  while (tr.walking || tr.leaf_n > 0) {
+  unsigned long long no_count = 0; /* lanes without a ray run begin() on a dummy ray: keep them out of the counters */
+  tr.begin(sc, sv, o, d, valid ? c_floor : no_count);
+#if PT_PRED_WALK
+  if (SWZ && MODE == PT_MODE_SIMD && PT_DIAG == 0) {
+    /* predicated form: wave-uniform loops, no divergent branches in the walk or the scan (node_step_pred).  Lanes
+     * whose ray is finished (or that entered without one: the caller passes `valid`) stay in the loops and commit
+     * nothing.  Same per-ray sequence of box and packet tests as below. */
+    tr.sp = (valid && tr.walking) ? 0 : -1;
+    for (;;) {
+      unsigned long long leafmask = __builtin_amdgcn_ballot_w64(tr.leaf_n > 0);
+      for (;;) {
+        const bool want = (tr.sp | -tr.leaf_n) >= 0; /* walking and not holding a leaf */
+        const unsigned long long wm = __builtin_amdgcn_ballot_w64(want);
+        if (wm == 0) break;
+        if ((int)__popcll(wm) < PT_WALK_MIN && leafmask != 0) break;
+        leafmask |= tr.node_step_pred(sv, stack, want, c_nodes, c_prims);
+      }
+      if (leafmask == 0) break; /* nobody walks (wm == 0: the other exit needs a held leaf) and nobody holds a leaf */
+      tr.packet_pred(sv);
+    }
+    return tr.r;
+  }
+#endif
+  while (valid && (tr.walking || tr.leaf_n > 0)) {
     for (;;) {
       /* keep walking while enough lanes still want a node step; once fewer than PT_WALK_MIN do and some lane
        * already holds a leaf, intersect the pending packets first (the stragglers resume afterwards) */
@@ -571,6 +744,9 @@ __device__ __forceinline__ PtTraceResult pt_trace_ray(const PtSceneDev& sc, cons
     }
     if (tr.leaf_n > 0) tr.packet(sv, c_nodes, c_floor);
   }
+#if PT_F32_FILTER_STATS
+  if (COUNT && SWZ) { c_floor += tr.n_undecided; c_floor += tr.n_wave_fallbacks << 32; }
+#endif
   return tr.r;
 }
 
@@ -604,11 +780,13 @@ __device__ __forceinline__ PtTraceResult pt_trace_packet(const PtSceneDev& sc, c
     for (;;) {
       /* the node's links: one address for the whole wave */
       uint32_t ua, ub, n_real;
-      if (SWZ) {
-        const unsigned char* nbase = sv.swz_nodes + (size_t)node * PT_SWZ_NODE_BYTES;
-        ua = (uint32_t)__builtin_amdgcn_readfirstlane((int)*(const uint32_t*)(nbase + 72));
-        ub = (uint32_t)__builtin_amdgcn_readfirstlane((int)*(const uint32_t*)(nbase + 76));
-        n_real = (ub >> 15) & 0x7fffu;
+      if (SWZ) { /* node = byte offset in the binary32 image */
+        const unsigned char* nbase = sv.swz_nodes + node;
+        const uint32_t w6 = (uint32_t)__builtin_amdgcn_readfirstlane((int)*(const uint32_t*)(nbase + 24));
+        const uint32_t w7 = (uint32_t)__builtin_amdgcn_readfirstlane((int)*(const uint32_t*)(nbase + 28));
+        ua = w6 & 0xffffu;
+        ub = (w6 >> 16) | ((w7 & 3u) << 30);
+        n_real = w6 >> 16;
       } else {
         const PtNode* np = sv.nodes + node;
         ua = (uint32_t)__builtin_amdgcn_readfirstlane((int)np->a);
@@ -626,7 +804,7 @@ __device__ __forceinline__ PtTraceResult pt_trace_packet(const PtSceneDev& sc, c
       if (hm != 0) {
         const uint32_t axis = ub >> 30;
         if (axis == PT_NODE_LEAF_AXIS) {
-          if (COUNT && hit) c_prims += (unsigned long long)(ub & (SWZ ? 0x7fffu : 0x3fffffffu));
+          if (COUNT && hit) c_prims += (unsigned long long)(SWZ ? (MODE == PT_MODE_SIMD ? ((n_real + 3u) & ~3u) : n_real) : (ub & 0x3fffffffu));
           if (MODE == PT_MODE_SIMD) {
             /* spheres_intersect_aux (lib.rs:102-178) in lockstep: slot k of the packet for every ray that hit the
              * leaf's box; the roots only where a ray's discriminant is >= +0 (same order per ray as packet()) */
@@ -657,6 +835,7 @@ __device__ __forceinline__ PtTraceResult pt_trace_packet(const PtSceneDev& sc, c
                 }
               }
             }
+            if (SWZ) tr.update_t32();
           } else if (hit) {
             tr.leaf_first = (int)ua;
             tr.leaf_n = (int)n_real;
@@ -712,23 +891,23 @@ __device__ __forceinline__ PtSceneView pt_scene_view(const PtSceneDev& sc, unsig
     double* l_tri = (double*)(lds_raw + off);
     if (MODE == PT_MODE_ARRAY && sc.has_triangles) off += (size_t)total_slots * 10 * sizeof(double);
     uint8_t* l_kind = (uint8_t*)(lds_raw + off);
-    /* nodes: expanded to the swizzled image while they are copied */
+    /* nodes: the binary32 filter image (PT_SWZ_NODE_BYTES each); links become byte offsets into it */
     for (int k = threadIdx.x; k < sc.n_nodes; k += blockDim.x) {
       const PtNode* src = sc.nodes + k;
-      double* dst = (double*)(l_nodes + (size_t)k * PT_SWZ_NODE_BYTES);
+      uint32_t* w = (uint32_t*)(l_nodes + (size_t)k * PT_SWZ_NODE_BYTES);
+      float mag = 0.0f;
       for (int ax = 0; ax < 3; ++ax) {
-        dst[3 * ax] = src->mn[ax];
-        dst[3 * ax + 1] = src->mx[ax];
-        dst[3 * ax + 2] = src->mn[ax];
+        const float lo = (float)src->mn[ax], hi = (float)src->mx[ax];
+        w[ax] = __float_as_uint(lo);
+        w[3 + ax] = __float_as_uint(hi);
+        mag = __builtin_fmaxf(mag, __builtin_fmaxf(__builtin_fabsf(lo), __builtin_fabsf(hi)));
       }
-      uint32_t* w = (uint32_t*)(dst + 9);
-      w[0] = src->a;
-      /* leaves: padded length | real slot count << 15 | tag, so that a visit reads one 8-byte link pair and nothing else */
-      w[1] = (src->b >> 30) == PT_NODE_LEAF_AXIS ? ((src->b & 0x7fffu) | ((src->pad[0] & 0x7fffu) << 15) | (PT_NODE_LEAF_AXIS << 30)) : src->b;
-      w[2] = src->pad[0];
-      w[3] = 0u;
-      w[4] = 0u;
-      w[5] = 0u;
+      const uint32_t axis = src->b >> 30;
+      const bool leaf = axis == PT_NODE_LEAF_AXIS;
+      w[6] = leaf ? ((src->a & 0xffffu) | ((src->pad[0] & 0xffffu) << 16))
+                  : ((src->a * PT_SWZ_NODE_BYTES) | (((src->b & 0x3fffffffu) * PT_SWZ_NODE_BYTES) << 16));
+      /* rounded up, then the two lowest mantissa bits carry the axis (a relative change below 2^-21, inside the slack) */
+      w[7] = ((__float_as_uint(mag * 1.000001f) + 4u) & ~3u) | axis;
     }
     {
       const uint4* src = (const uint4*)sc.sph;
@@ -913,11 +1092,12 @@ __global__ __launch_bounds__(PT_TRACE_BLOCK_OF(MODE, LDS_SCENE), (LDS_SCENE && M
         d = v3(q.dx[i], q.dy[i], q.dz[i]);
       }
     }
-    if (valid) {
-      if (COUNT) c_seg++;
+    {
+      if (COUNT && valid) c_seg++;
       const unsigned long long diag_n0 = c_nodes;
-      const PtTraceResult r = pt_trace_ray<MODE, COUNT, PRIMARY, StackT, LDS_SCENE>(sc, sv, stack, o, d, c_nodes, c_prims, c_floor);
-      if (COUNT && PT_DIAG == 2 && !PRIMARY) {
+      /* every lane goes in (the predicated walk has wave-uniform loops); lanes without a ray commit nothing */
+      const PtTraceResult r = pt_trace_ray<MODE, COUNT, PRIMARY, StackT, LDS_SCENE>(sc, sv, stack, o, d, c_nodes, c_prims, c_floor, valid);
+      if (COUNT && PT_DIAG == 2 && !PRIMARY && valid) {
         unsigned long long m = c_nodes - diag_n0;
         for (int off = 32; off > 0; off >>= 1) {
           const unsigned long long other = __shfl_xor(m, off);
@@ -926,11 +1106,13 @@ __global__ __launch_bounds__(PT_TRACE_BLOCK_OF(MODE, LDS_SCENE), (LDS_SCENE && M
         PT_DIAG_WAVE_SLOTS(c_floor);
         if (lane == 0) c_floor += m * 64 - 64;
       }
-      hits.t[i] = r.t;
-      hits.slot[i] = r.slot;
-      if (MODE == PT_MODE_ARRAY && sc.has_triangles) {
-        hits.u[i] = r.u;
-        hits.v[i] = r.v;
+      if (valid) {
+        hits.t[i] = r.t;
+        hits.slot[i] = r.slot;
+        if (MODE == PT_MODE_ARRAY && sc.has_triangles) {
+          hits.u[i] = r.u;
+          hits.v[i] = r.v;
+        }
       }
     }
   }
@@ -1092,9 +1274,9 @@ __device__ __forceinline__ Quat pt_quat_conj(Quat q) {
 }
 
 /* Texture.eval (texture.ml:16-31) */
-__device__ __forceinline__ V3 pt_texture_eval(const PtTexture& t, double u, double v) {
-  if (t.kind == 0) return v3(t.even[0], t.even[1], t.even[2]);
-  const double width = (double)(t.width - 1), height = (double)(t.height - 1);
+__device__ __forceinline__ V3 pt_texture_eval(const PtShadeRec& t, double u, double v) {
+  if (t.tex_kind == 0) return v3(t.even[0], t.even[1], t.even[2]);
+  const double width = (double)(t.tex_w - 1), height = (double)(t.tex_h - 1);
   const double xp = u * width, yp = v * height;
   const long long px = ((long long)xp) & 1, py = ((long long)yp) & 1; /* Float.to_int a land 1 */
   if (px == py) return v3(t.even[0], t.even[1], t.even[2]);
@@ -1125,17 +1307,17 @@ struct PtSurface {
   V3 omega_i;       /* Shader_space.omega_i */
   double tu, tv;    /* Texture.Coord */
   bool hit_front;
-  PtMaterial m;
+  const PtShadeRec* m; /* the slot's material and texture: read field by field, never copied (96 B would go to scratch) */
 };
 __device__ __forceinline__ PtSurface pt_surface_hit(const PtSceneDev& sc, V3 o, V3 d, int slot, double t_hit, double bu,
                                                     double bv) {
   const double pi = 3.14159265358979323846;
   PtSurface sf;
-  sf.m = sc.materials[sc.slot_material[slot]];
+  sf.m = sc.slot_shade + slot;
   sf.tu = 0.0;
   sf.tv = 0.0;
-  const PtMaterial& m = sf.m;
-  const bool need_uv = (m.kind != 2) && (sc.textures[m.texture].kind != 0);
+  const PtShadeRec& m = *sf.m;
+  const bool need_uv = (m.kind != 2) && (m.tex_kind != 0);
   if (sc.slot_kind[slot] == PT_SLOT_SPHERE) {
     /* Sphere.hit (sphere.ml:56-69) */
     const double* s = sc.sph + (size_t)slot * 4;
@@ -1178,21 +1360,21 @@ struct PtScatter {
   V3 attenuation, wo;
 };
 __device__ __forceinline__ PtScatter pt_material_scatter(const PtSceneDev& sc, const PtSurface& sf, double su) {
-  const PtMaterial& m = sf.m;
+  const PtShadeRec& m = *sf.m;
   const V3 omega_i = sf.omega_i;
   PtScatter r;
   r.attenuation = v3(1.0, 1.0, 1.0);
   r.wo = v3(0.0, 0.0, 0.0);
   if (m.kind == 0) {
     r.kind = 2;
-    r.attenuation = pt_texture_eval(sc.textures[m.texture], sf.tu, sf.tv);
+    r.attenuation = pt_texture_eval(m, sf.tu, sf.tv);
   } else if (m.kind == 1) {
     const V3 omega_r = v3(-omega_i.x, -omega_i.y, omega_i.z); /* Shader_space.reflect */
     if (omega_r.z <= 0.0) {
       r.kind = 0;
     } else {
       r.kind = 1;
-      const V3 a = pt_texture_eval(sc.textures[m.texture], sf.tu, sf.tv);
+      const V3 a = pt_texture_eval(m, sf.tu, sf.tv);
       const double sp5 = pt_pow5(1.0 - omega_i.z);
       const V3 c = v3_scale(v3_sub(v3(1.0, 1.0, 1.0), a), sp5);
       r.attenuation = v3_add(a, c);
@@ -1448,7 +1630,7 @@ __global__ __launch_bounds__(PT_SHADE_BLOCK, PT_SHADE_WAVES) void k_shade(PtScen
         const double t_hit = hits.t[i];
         const bool is_tri = sc.slot_kind[slot] != PT_SLOT_SPHERE;
         const PtSurface sf = pt_surface_hit(sc, o, d, slot, t_hit, is_tri ? hits.u[i] : 0.0, is_tri ? hits.v[i] : 0.0);
-        const PtMaterial& m = sf.m;
+        const PtShadeRec& m = *sf.m;
         const V3 point = sf.point;
         const Quat rot_inv = pt_quat_conj(sf.rot);
         const V3 emit = EMIT ? v3(m.emit[0], m.emit[1], m.emit[2]) : v3(0.0, 0.0, 0.0);

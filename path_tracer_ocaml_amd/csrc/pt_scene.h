@@ -61,6 +61,20 @@ struct PtTexture { /* 64 B */
   double pad2;
 };
 
+/* What shading one hit on a slot needs besides the slot's geometry, in ONE 96-byte record per slot: material kind /
+ * index / emission and the texture it points at.  The shade stage used to reach this through three dependent gathers
+ * (slot -> slot_material -> materials -> textures: each ~1-2 us under load, with the kernel 70 % of its time parked on
+ * s_waitcnt); now the hop after the hit slot is the last one. */
+struct __attribute__((aligned(16))) PtShadeRec {
+  int32_t kind;     /* PTX_MAT_* */
+  int32_t tex_kind; /* PTX_TEX_* (Lambertian / Metal) */
+  int32_t tex_w, tex_h;
+  double index;
+  double even[3];
+  double odd[3];
+  double emit[3];
+};
+
 /* everything a kernel needs, passed by value (pointers are device pointers) */
 struct PtSceneDev {
   const PtNode* nodes;
@@ -83,6 +97,7 @@ struct PtSceneDev {
   int32_t has_checker;
   const PtMaterial* materials;
   const PtTexture* textures;
+  const PtShadeRec* slot_shade; /* per slot (padding slots zero) */
   double cam_llx, cam_lly, cam_vx, cam_vy;
   int32_t bg_kind;
   int32_t pad0;
