@@ -275,9 +275,6 @@ struct PtTraceResult {
 #ifndef PT_WALK_MIN
 #define PT_WALK_MIN 8
 #endif
-#ifndef PT_PRED_WALK
-#define PT_PRED_WALK 0 /* 1: the predicated (scalar-lean) walk and scan for LDS-resident Simd_leaf scenes (measured: halves the scalar instructions, +25 % vector instructions, +3x LDS bank conflicts: 5 % slower) */
-#endif
 /* PT_DIAG (diagnostic builds only, tools/diag_utilisation.sh): re-purposes the COUNT counters of SECONDARY launches
  * to measure lane utilisation per traversal phase: nodes = useful lane steps, floor = lane slots the wave spent.
  * 1: node walk   2: node walk if only the per-chunk tail were lost   3: packet scan   4: packet heavy part */
@@ -386,25 +383,6 @@ struct PtTraverser {
     const double t_min = 0.0;
     bool hit;
     if (SWZ) {
-#if defined(PT_DUMMY_VALU) || defined(PT_DUMMY_F64) || defined(PT_DUMMY_SALU)
-      { /* sensitivity experiment (tools/bench_variants.sh): extra instructions of one kind per node test */
-        float xv = fix; double xd = r.t; int xs = (int)nd;
-        (void)xv; (void)xd; (void)xs;
-#ifdef PT_DUMMY_VALU
-#pragma unroll
-        for (int q = 0; q < PT_DUMMY_VALU; ++q) asm volatile("v_add_f32 %0, %0, %0" : "+v"(xv));
-#endif
-#ifdef PT_DUMMY_F64
-#pragma unroll
-        for (int q = 0; q < PT_DUMMY_F64; ++q) asm volatile("v_add_f64 %0, %0, %0" : "+v"(xd));
-#endif
-#ifdef PT_DUMMY_SALU
-        int ss = __builtin_amdgcn_readfirstlane(xs);
-#pragma unroll
-        for (int q = 0; q < PT_DUMMY_SALU; ++q) asm volatile("s_add_u32 %0, %0, 1" : "+s"(ss));
-#endif
-      }
-#endif
       /* nd is the node's BYTE offset in the binary32 image */
       const uint4 w0 = *(const uint4*)(sv.swz_nodes + nd), w1 = *(const uint4*)(sv.swz_nodes + nd + 16);
       na = w1.z & 0xffffu;
@@ -475,93 +453,6 @@ struct PtTraverser {
         node = PT_STACK_POP(stack, sp);
       }
     }
-  }
-
-  /* The same visit with NO divergent control flow (LDS-resident scenes): every lane executes the whole step and the
-   * lanes that do not `want` one commit nothing.  Why: on this chip a CU has ONE scalar unit for its four SIMDs, and the
-   * exec-mask bookkeeping the compiler emits for nested divergent branches (s_and_saveexec / s_or / s_andn2 per `if`,
-   * loop-exit masks per `break`) made the walk scalar-bound -- ~45 scalar instructions per node test; adding 20 more
-   * slowed the kernel as much as 50 extra binary32 vector instructions did (tools/bench_variants.sh ds20 / dv10).
-   * Here the masks only feed v_cndmask.  The far child is stored above the top of the stack unconditionally (harmless
-   * when the lane does not descend) and the entry a pop would take is read at the top of the step, beside the node.
-   * Returns the lanes that took a leaf.  SWZ only. */
-  __device__ __forceinline__ unsigned long long node_step_pred(const PtSceneView& sv, StackT* stack, bool want,
-                                                               unsigned long long& c_nodes, unsigned long long& c_prims) {
-    /* State lives in integers and is updated with bit masks (0 / ~0 -> v_bfi_b32, v_and, v_or): a `bool` that
-     * survives the loop becomes a lane mask in scalar registers and every update of it costs 2-3 scalar instructions.
-     * walking <=> sp >= 0 here (sp = -1: the ray has run out of nodes). */
-    if (COUNT) c_nodes += want ? 1ull : 0ull;
-    const int32_t wantm = want ? -1 : 0;
-    const int32_t spc = sp > 0 ? sp : 0;
-    const uint32_t popped = PT_STACK_POP(stack, spc > 0 ? spc - 1 : 0);
-    uint32_t na, nb, n_real;
-    const int32_t hitm = (test_box(sv, node, na, nb, n_real, want) ? -1 : 0) & wantm;
-    const uint32_t axis = nb >> 30;
-    const int32_t leafm = ((int32_t)((axis + 1u) << 29)) >> 31; /* axis == 3 <=> bit 2 of axis + 1 */
-    const int32_t takem = hitm & leafm, descm = hitm & ~leafm;
-    const uint32_t lhs = na, rhs = nb & 0x3fffffffu;
-    const int32_t lfm = -(int32_t)((dirs >> axis) & 1u); /* lhs first */
-    const uint32_t nearc = (lhs & (uint32_t)lfm) | (rhs & ~(uint32_t)lfm);
-    const uint32_t farc = (rhs & (uint32_t)lfm) | (lhs & ~(uint32_t)lfm);
-    PT_STACK_PUSH(stack, spc, farc); /* above the top unless `desc` moves the top past it */
-    const int32_t popm = wantm & ~descm;
-    const int32_t morem = ~((sp - 1) >> 31); /* sp > 0 */
-    const int32_t pmm = popm & morem, finm = popm & ~morem;
-    const uint32_t keep = (popped & (uint32_t)pmm) | (node & ~(uint32_t)pmm);
-    node = (nearc & (uint32_t)descm) | (keep & ~(uint32_t)descm);
-    sp = (sp - descm + pmm) | finm;
-    leaf_first = (int)(((uint32_t)na & (uint32_t)takem) | ((uint32_t)leaf_first & ~(uint32_t)takem));
-    leaf_n = (int)((n_real & (uint32_t)takem) | ((uint32_t)leaf_n & ~(uint32_t)takem));
-    if (COUNT) c_prims += takem ? (unsigned long long)(MODE == PT_MODE_SIMD ? ((n_real + 3u) & ~3u) : n_real) : 0ull;
-    return __builtin_amdgcn_ballot_w64(takem != 0);
-  }
-
-  /* Simd_leaf packets for every lane that holds a leaf, with wave-uniform loop bounds (see node_step_pred): the scan
-   * runs k = 0 .. (longest held packet) - 1 for all lanes and a lane beyond its own packet contributes no candidate. */
-  __device__ __forceinline__ void packet_pred(const PtSceneView& sv) {
-    const double t_min = 0.0;
-    const bool held = leaf_n > 0;
-    for (int base = 0;; base += 32) {
-      uint32_t cand = 0;
-      for (int k = 0; k < 32; ++k) {
-        const bool in = base + k < leaf_n;
-        if (__builtin_amdgcn_ballot_w64(in) == 0) break;
-        const double* s = sv.sph + (size_t)(leaf_first + (in ? base + k : 0)) * 4;
-        const double fx = ORIGIN_ZERO ? s[0] : s[0] - o.x, fy = ORIGIN_ZERO ? s[1] : s[1] - o.y,
-                     fz = ORIGIN_ZERO ? s[2] : s[2] - o.z;
-        const double bp_over_a = pt_fma(fx, d.x, pt_fma(fy, d.y, fz * d.z)) * one_over_a;
-        const double wx = pt_fma(d.x, bp_over_a, -fx);
-        const double wy = pt_fma(d.y, bp_over_a, -fy);
-        const double wz = pt_fma(d.z, bp_over_a, -fz);
-        const double disc = (s[3] * s[3]) - pt_fma(wx, wx, pt_fma(wy, wy, wz * wz));
-        cand |= (in && (disc == disc) && !pt_signbit(disc)) ? (1u << k) : 0u;
-      }
-      while (cand != 0) { /* the roots of the candidates, in slot order (lib.rs:169-177: last index wins ties) */
-        const int k = __ffs((int)cand) - 1;
-        cand &= cand - 1u;
-        const double* s = sv.sph + (size_t)(leaf_first + base + k) * 4;
-        const double fx = ORIGIN_ZERO ? s[0] : s[0] - o.x, fy = ORIGIN_ZERO ? s[1] : s[1] - o.y,
-                     fz = ORIGIN_ZERO ? s[2] : s[2] - o.z;
-        const double r2 = s[3] * s[3];
-        const double c = pt_fma(fx, fx, pt_fma(fy, fy, fz * fz)) - r2;
-        const double bp = pt_fma(fx, d.x, pt_fma(fy, d.y, fz * d.z));
-        const double bp_over_a = bp * one_over_a;
-        const double wx = pt_fma(d.x, bp_over_a, -fx);
-        const double wy = pt_fma(d.y, bp_over_a, -fy);
-        const double wz = pt_fma(d.z, bp_over_a, -fz);
-        const double disc = r2 - pt_fma(wx, wx, pt_fma(wy, wy, wz * wz));
-        const double q_rhs = pt_sqrt(qa * disc);
-        const double qq = pt_signbit(bp) ? (bp - q_rhs) : (bp + q_rhs);
-        const double t = pt_signbit(c) ? (qq * one_over_a) : (c / qq);
-        if (!(t < t_min) && t <= r.t) {
-          r.t = t;
-          r.slot = leaf_first + base + k;
-        }
-      }
-      if (__builtin_amdgcn_ballot_w64(base + 32 < leaf_n) == 0) break;
-    }
-    leaf_n = 0;
-    if (held && SWZ) update_t32();
   }
 
   /* Leaf.intersect on the held leaf (caller checks leaf_n > 0) */
@@ -709,27 +600,6 @@ __device__ __forceinline__ PtTraceResult pt_trace_ray(const PtSceneDev& sc, cons
   PtTraverser<MODE, COUNT, ORIGIN_ZERO, StackT, SWZ> tr;
   unsigned long long no_count = 0; /* lanes without a ray run begin() on a dummy ray: keep them out of the counters */
   tr.begin(sc, sv, o, d, valid ? c_floor : no_count);
-#if PT_PRED_WALK
-  if (SWZ && MODE == PT_MODE_SIMD && PT_DIAG == 0) {
-    /* predicated form: wave-uniform loops, no divergent branches in the walk or the scan (node_step_pred).  Lanes
-     * whose ray is finished (or that entered without one: the caller passes `valid`) stay in the loops and commit
-     * nothing.  Same per-ray sequence of box and packet tests as below. */
-    tr.sp = (valid && tr.walking) ? 0 : -1;
-    for (;;) {
-      unsigned long long leafmask = __builtin_amdgcn_ballot_w64(tr.leaf_n > 0);
-      for (;;) {
-        const bool want = (tr.sp | -tr.leaf_n) >= 0; /* walking and not holding a leaf */
-        const unsigned long long wm = __builtin_amdgcn_ballot_w64(want);
-        if (wm == 0) break;
-        if ((int)__popcll(wm) < PT_WALK_MIN && leafmask != 0) break;
-        leafmask |= tr.node_step_pred(sv, stack, want, c_nodes, c_prims);
-      }
-      if (leafmask == 0) break; /* nobody walks (wm == 0: the other exit needs a held leaf) and nobody holds a leaf */
-      tr.packet_pred(sv);
-    }
-    return tr.r;
-  }
-#endif
   while (valid && (tr.walking || tr.leaf_n > 0)) {
     for (;;) {
       /* keep walking while enough lanes still want a node step; once fewer than PT_WALK_MIN do and some lane
@@ -1309,6 +1179,9 @@ struct PtSurface {
   bool hit_front;
   const PtShadeRec* m; /* the slot's material and texture: read field by field, never copied (96 B would go to scratch) */
 };
+/* CAT: the shading category when the caller knows it at compile time (per-category shade kernels), PT_CAT_NONE when it
+ * has to be read from the slot's record */
+template <int CAT = PT_CAT_NONE>
 __device__ __forceinline__ PtSurface pt_surface_hit(const PtSceneDev& sc, V3 o, V3 d, int slot, double t_hit, double bu,
                                                     double bv) {
   const double pi = 3.14159265358979323846;
@@ -1317,7 +1190,9 @@ __device__ __forceinline__ PtSurface pt_surface_hit(const PtSceneDev& sc, V3 o, 
   sf.tu = 0.0;
   sf.tv = 0.0;
   const PtShadeRec& m = *sf.m;
-  const bool need_uv = (m.kind != 2) && (m.tex_kind != 0);
+  /* tex_coord feeds Texture.eval only, and only a checker reads it */
+  const bool need_uv = CAT == PT_CAT_LAMBERT_SOLID || CAT == PT_CAT_DIELECTRIC ? false
+                       : (CAT == PT_CAT_LAMBERT_CHECKER ? true : ((m.kind != 2) && (m.tex_kind != 0)));
   if (sc.slot_kind[slot] == PT_SLOT_SPHERE) {
     /* Sphere.hit (sphere.ml:56-69) */
     const double* s = sc.sph + (size_t)slot * 4;
@@ -1359,16 +1234,19 @@ struct PtScatter {
   int kind;
   V3 attenuation, wo;
 };
+template <int CAT = PT_CAT_NONE>
 __device__ __forceinline__ PtScatter pt_material_scatter(const PtSceneDev& sc, const PtSurface& sf, double su) {
   const PtShadeRec& m = *sf.m;
   const V3 omega_i = sf.omega_i;
   PtScatter r;
   r.attenuation = v3(1.0, 1.0, 1.0);
   r.wo = v3(0.0, 0.0, 0.0);
-  if (m.kind == 0) {
+  const int mkind = (CAT == PT_CAT_LAMBERT_SOLID || CAT == PT_CAT_LAMBERT_CHECKER) ? 0
+                    : (CAT == PT_CAT_METAL ? 1 : (CAT == PT_CAT_DIELECTRIC ? 2 : m.kind));
+  if (mkind == 0) {
     r.kind = 2;
     r.attenuation = pt_texture_eval(m, sf.tu, sf.tv);
-  } else if (m.kind == 1) {
+  } else if (mkind == 1) {
     const V3 omega_r = v3(-omega_i.x, -omega_i.y, omega_i.z); /* Shader_space.reflect */
     if (omega_r.z <= 0.0) {
       r.kind = 0;
@@ -1513,6 +1391,117 @@ __device__ __forceinline__ uint32_t pt_block_sort_by_category(int key, uint32_t*
   return (uint32_t)perm[threadIdx.x];
 }
 
+/* What one segment leaves behind: either the path's final colour (written to `contrib` inside) or the next ray. */
+struct PtShadeOut {
+  bool keep;
+  V3 n_o, n_d, n_attn, n_emit;
+  uint32_t id;
+  int offset;
+};
+/* The body of `loop` in Integrator.path_tracer (integrator.ml:30-66) for entry i of the queue (PRIMARY: virtual
+ * entry i = a camera sample).  CAT = the entry's shading category if the kernel is specialised for one. */
+template <bool EMIT, bool PRIMARY, int CAT>
+__device__ __forceinline__ void pt_shade_entry(const PtSceneDev& sc, const PtQueue& q, const PtHits& hits, const PtContrib& contrib,
+                                               const double* __restrict__ alpha, int bounce, int last_bounce,
+                                               const PtGenParams& g, uint32_t i, bool live, PtShadeOut& so) {
+    const double pi = 3.14159265358979323846;
+    bool keep = false;
+    V3 n_o = v3(0, 0, 0), n_d = v3(0, 0, 0), n_attn = v3(0, 0, 0), n_emit = v3(0, 0, 0);
+    uint32_t id = 0;
+    int offset = 0;
+    PtPrimarySample ps;
+    if (PRIMARY && live) {
+      ps = pt_primary_decode(g, i);
+      live = ps.valid;
+    }
+    if (live) {
+      V3 o, d, attn0, emit0 = v3(0.0, 0.0, 0.0);
+      if (PRIMARY) {
+        o = v3(0.0, 0.0, 0.0);
+        d = pt_primary_dir(sc, g, ps, alpha);
+        attn0 = v3(1.0, 1.0, 1.0); /* Color.white, integrator.ml:68 */
+        id = ps.id;
+        offset = ps.offset;
+      } else {
+        o = v3(q.ox[i], q.oy[i], q.oz[i]);
+        d = v3(q.dx[i], q.dy[i], q.dz[i]);
+        attn0 = v3(q.ar[i], q.ag[i], q.ab[i]);
+        if (EMIT) emit0 = v3(q.er[i], q.eg[i], q.eb[i]);
+        id = q.id[i];
+        offset = q.offset[i];
+      }
+      const int slot = CAT == PT_CAT_MISS ? -1 : hits.slot[i];
+      V3 result = v3(0, 0, 0);
+      bool done = true;
+      if (CAT == PT_CAT_MISS || (CAT == PT_CAT_NONE && slot < 0)) {
+        /* None -> add_mul emit0 attn0 (background ray), integrator.ml:36 */
+        result = v3_fma(attn0, pt_background(sc, d), emit0);
+      } else {
+        const double t_hit = hits.t[i];
+        const bool is_tri = sc.slot_kind[slot] != PT_SLOT_SPHERE;
+        const PtSurface sf = pt_surface_hit<CAT>(sc, o, d, slot, t_hit, is_tri ? hits.u[i] : 0.0, is_tri ? hits.v[i] : 0.0);
+        const PtShadeRec& m = *sf.m;
+        const V3 point = sf.point;
+        const Quat rot_inv = pt_quat_conj(sf.rot);
+        const V3 emit = EMIT ? v3(m.emit[0], m.emit[1], m.emit[2]) : v3(0.0, 0.0, 0.0);
+        /* take_2d (), integrator.ml:20-28,39: dims 2+2k, 3+2k for the k-th hit */
+        const double su = pt_lds_get(alpha, offset, 2 + 2 * bounce);
+        const double sv = pt_lds_get(alpha, offset, 3 + 2 * bounce);
+        const PtScatter scat = pt_material_scatter<CAT>(sc, sf, su);
+        const int sc_kind = scat.kind;
+        V3 attenuation = scat.attenuation;
+        V3 wo = scat.wo;
+
+        if (sc_kind == 0) {
+          result = v3_fma(attn0, emit, emit0); /* Absorb, integrator.ml:41 */
+        } else {
+          bool scatter_ok = true;
+          if (sc_kind == 2) {
+            /* Pdf.sample / Pdf.eval (pdf.ml:5-15, shader_space.ml:56-64) */
+            const double r = pt_sqrt(su);
+            const double theta = sv * 2.0 * pi;
+            double sn, cs;
+            pt_sincos(theta, &sn, &cs);
+            wo = v3(r * cs, r * sn, pt_sqrt(1.0 - su));
+            const double diffuse_pd = (wo.z < 0.0) ? 0.0 : wo.z / pi;
+            if (diffuse_pd == 0.0) {
+              scatter_ok = false;
+            } else {
+              const double pd = diffuse_pd / diffuse_pd; /* divisor = Pdf.eval diffuse_plus_light = the same */
+              if (!pt_isfinite(pd)) scatter_ok = false;
+              else attenuation = v3_scale(attenuation, pd);
+            }
+          }
+          if (!scatter_ok) {
+            result = v3_fma(attn0, emit, emit0); /* integrator.ml:53,58 */
+          } else {
+            /* Shader_space.world_ray (shader_space.ml:51-54) */
+            const V3 dir = pt_quat_transform(rot_inv, wo);
+            n_o = v3_add(point, v3_scale(dir, 1e-3));
+            n_d = dir;
+            n_emit = v3_fma(attenuation, emit0, emit); /* add_mul emit attenuation emit0 */
+            n_attn = v3_mul(attenuation, attn0);
+            if (last_bounce) {
+              /* the recursive call sees max_bounces <= 0: add_mul emit0 attn0 Color.black (integrator.ml:31-32) */
+              result = v3_fma(n_attn, v3(0.0, 0.0, 0.0), n_emit);
+            } else {
+              done = false;
+            }
+          }
+        }
+      }
+      if (done) {
+        contrib.rgbx[id] = make_double4(result.x, result.y, result.z, 0.0);
+      } else {
+        keep = true;
+      }
+    }
+    so.keep = keep;
+    so.n_o = n_o; so.n_d = n_d; so.n_attn = n_attn; so.n_emit = n_emit;
+    so.id = id;
+    so.offset = offset;
+}
+
 #ifndef PT_SHADE_BLOCK
 #define PT_SHADE_BLOCK 512 /* <= 512: the category / bin tables are scanned by one wave (<= 64 entries) */
 #endif
@@ -1535,7 +1524,6 @@ __global__ __launch_bounds__(PT_SHADE_BLOCK, PT_SHADE_WAVES) void k_shade(PtScen
   __shared__ uint16_t lds_perm[PT_SHADE_BLOCK];
   __shared__ uint32_t lds_win[2];
   const uint32_t n = PRIMARY ? n_primary : *q.count;
-  const double pi = 3.14159265358979323846;
 
   /* Windows of blockDim entries are handed out dynamically (PtChunkFeed's counters, one atomic per window by
    * thread 0).  The workgroup always knows its next THREE windows (wA now, wB, wC): the sort key of an entry is two
@@ -1594,98 +1582,12 @@ __global__ __launch_bounds__(PT_SHADE_BLOCK, PT_SHADE_WAVES) void k_shade(PtScen
       }
       i = base_i + pt_block_sort_by_category(key, lds_cnt, lds_perm);
     }
-    bool live = i < n;
-    bool keep = false;
-    V3 n_o = v3(0, 0, 0), n_d = v3(0, 0, 0), n_attn = v3(0, 0, 0), n_emit = v3(0, 0, 0);
-    uint32_t id = 0;
-    int offset = 0;
-    PtPrimarySample ps;
-    if (PRIMARY && live) {
-      ps = pt_primary_decode(g, i);
-      live = ps.valid;
-    }
-    if (live) {
-      V3 o, d, attn0, emit0 = v3(0.0, 0.0, 0.0);
-      if (PRIMARY) {
-        o = v3(0.0, 0.0, 0.0);
-        d = pt_primary_dir(sc, g, ps, alpha);
-        attn0 = v3(1.0, 1.0, 1.0); /* Color.white, integrator.ml:68 */
-        id = ps.id;
-        offset = ps.offset;
-      } else {
-        o = v3(q.ox[i], q.oy[i], q.oz[i]);
-        d = v3(q.dx[i], q.dy[i], q.dz[i]);
-        attn0 = v3(q.ar[i], q.ag[i], q.ab[i]);
-        if (EMIT) emit0 = v3(q.er[i], q.eg[i], q.eb[i]);
-        id = q.id[i];
-        offset = q.offset[i];
-      }
-      const int slot = hits.slot[i];
-      V3 result = v3(0, 0, 0);
-      bool done = true;
-      if (slot < 0) {
-        /* None -> add_mul emit0 attn0 (background ray), integrator.ml:36 */
-        result = v3_fma(attn0, pt_background(sc, d), emit0);
-      } else {
-        const double t_hit = hits.t[i];
-        const bool is_tri = sc.slot_kind[slot] != PT_SLOT_SPHERE;
-        const PtSurface sf = pt_surface_hit(sc, o, d, slot, t_hit, is_tri ? hits.u[i] : 0.0, is_tri ? hits.v[i] : 0.0);
-        const PtShadeRec& m = *sf.m;
-        const V3 point = sf.point;
-        const Quat rot_inv = pt_quat_conj(sf.rot);
-        const V3 emit = EMIT ? v3(m.emit[0], m.emit[1], m.emit[2]) : v3(0.0, 0.0, 0.0);
-        /* take_2d (), integrator.ml:20-28,39: dims 2+2k, 3+2k for the k-th hit */
-        const double su = pt_lds_get(alpha, offset, 2 + 2 * bounce);
-        const double sv = pt_lds_get(alpha, offset, 3 + 2 * bounce);
-        const PtScatter scat = pt_material_scatter(sc, sf, su);
-        const int sc_kind = scat.kind;
-        V3 attenuation = scat.attenuation;
-        V3 wo = scat.wo;
-
-        if (sc_kind == 0) {
-          result = v3_fma(attn0, emit, emit0); /* Absorb, integrator.ml:41 */
-        } else {
-          bool scatter_ok = true;
-          if (sc_kind == 2) {
-            /* Pdf.sample / Pdf.eval (pdf.ml:5-15, shader_space.ml:56-64) */
-            const double r = pt_sqrt(su);
-            const double theta = sv * 2.0 * pi;
-            double sn, cs;
-            pt_sincos(theta, &sn, &cs);
-            wo = v3(r * cs, r * sn, pt_sqrt(1.0 - su));
-            const double diffuse_pd = (wo.z < 0.0) ? 0.0 : wo.z / pi;
-            if (diffuse_pd == 0.0) {
-              scatter_ok = false;
-            } else {
-              const double pd = diffuse_pd / diffuse_pd; /* divisor = Pdf.eval diffuse_plus_light = the same */
-              if (!pt_isfinite(pd)) scatter_ok = false;
-              else attenuation = v3_scale(attenuation, pd);
-            }
-          }
-          if (!scatter_ok) {
-            result = v3_fma(attn0, emit, emit0); /* integrator.ml:53,58 */
-          } else {
-            /* Shader_space.world_ray (shader_space.ml:51-54) */
-            const V3 dir = pt_quat_transform(rot_inv, wo);
-            n_o = v3_add(point, v3_scale(dir, 1e-3));
-            n_d = dir;
-            n_emit = v3_fma(attenuation, emit0, emit); /* add_mul emit attenuation emit0 */
-            n_attn = v3_mul(attenuation, attn0);
-            if (last_bounce) {
-              /* the recursive call sees max_bounces <= 0: add_mul emit0 attn0 Color.black (integrator.ml:31-32) */
-              result = v3_fma(n_attn, v3(0.0, 0.0, 0.0), n_emit);
-            } else {
-              done = false;
-            }
-          }
-        }
-      }
-      if (done) {
-        contrib.rgbx[id] = make_double4(result.x, result.y, result.z, 0.0);
-      } else {
-        keep = true;
-      }
-    }
+    PtShadeOut so;
+    pt_shade_entry<EMIT, PRIMARY, PT_CAT_NONE>(sc, q, hits, contrib, alpha, bounce, last_bounce, g, i, i < n, so);
+    const bool keep = so.keep;
+    const V3 n_o = so.n_o, n_d = so.n_d, n_attn = so.n_attn, n_emit = so.n_emit;
+    const uint32_t id = so.id;
+    const int offset = so.offset;
 #if PT_APPEND_BINS > 1
     const int octant = (n_d.x >= 0.0 ? 1 : 0) | (n_d.y >= 0.0 ? 2 : 0) | (n_d.z >= 0.0 ? 4 : 0);
     /* with the category sort on, its three barriers separate one append from the next */
@@ -1712,6 +1614,135 @@ __global__ __launch_bounds__(PT_SHADE_BLOCK, PT_SHADE_WAVES) void k_shade(PtScen
 #endif
   }
 #undef PT_WIN_BASE
+}
+
+/* ------------------------------------------------------------------ per-stage queues for the shade stage
+ * One index list per shading category (miss / Lambertian solid / Lambertian checker / metal / dielectric), built by
+ * k_classify right after the trace launch, and one shade kernel per list (k_shade_cat).  With ONE kernel over a
+ * category-sorted 512-entry window, the window's waves ran different materials of very different length (a miss is
+ * ~150 instructions, a checker Lambertian ~1200) between the same workgroup barriers: the short waves sat parked at the
+ * barrier (SQ_WAIT_ANY 72 % of a wave's life, profiles/r02a_sq.json) and the register file was sized for the sum of
+ * all five paths.  Per-category kernels keep every wave of a workgroup on the same path, need no sort, and are
+ * register-allocated for one material each.  A list keeps queue order, so reads of the SoA queues stay clustered. */
+struct PtCatLists {
+  uint32_t* idx;      /* PT_N_SHADE_CAT lists of `cap` entries each: queue (or virtual primary) indices */
+  uint32_t* count;    /* PT_N_SHADE_CAT list lengths (device, zero at launch) */
+  size_t cap;
+};
+#define PT_N_SHADE_CAT 5 /* PT_CAT_MISS .. PT_CAT_DIELECTRIC */
+#define PT_CLASSIFY_BLOCK 1024
+#define PT_CLASSIFY_ROWS 4 /* entries per thread per iteration: 4096 entries, 5 atomics */
+
+template <bool PRIMARY>
+__global__ __launch_bounds__(PT_CLASSIFY_BLOCK) void k_classify(PtSceneDev sc, const uint32_t* __restrict__ q_count, PtHits hits,
+                                                               PtGenParams g, uint32_t n_primary, PtCatLists lists) {
+  __shared__ uint32_t cnt[PT_N_SHADE_CAT][PT_CLASSIFY_ROWS * (PT_CLASSIFY_BLOCK / 64) + 1]; /* [category][row], row = j * 16 + wave */
+  __shared__ uint32_t base_of[PT_N_SHADE_CAT];
+  const uint32_t n = PRIMARY ? n_primary : *q_count;
+  const int lane = pt_lane(), wave = (int)(threadIdx.x >> 6);
+  constexpr int kRows = PT_CLASSIFY_ROWS * (PT_CLASSIFY_BLOCK / 64);
+  const unsigned long long span = (unsigned long long)PT_CLASSIFY_BLOCK * PT_CLASSIFY_ROWS;
+  for (unsigned long long base = (unsigned long long)blockIdx.x * span; base < n; base += (unsigned long long)gridDim.x * span) {
+    int cat[PT_CLASSIFY_ROWS];
+    uint32_t rank[PT_CLASSIFY_ROWS];
+#pragma unroll
+    for (int j = 0; j < PT_CLASSIFY_ROWS; ++j) {
+      const unsigned long long i = base + (unsigned long long)j * PT_CLASSIFY_BLOCK + threadIdx.x;
+      int c = PT_CAT_NONE;
+      if (i < n) {
+        bool ok = true;
+        if (PRIMARY) ok = pt_primary_decode(g, (uint32_t)i).valid;
+        if (ok) {
+          const int sl = hits.slot[i];
+          c = sl < 0 ? PT_CAT_MISS : (int)sc.slot_cat[sl];
+        }
+      }
+      cat[j] = c;
+      rank[j] = 0;
+#pragma unroll
+      for (int k = 0; k < PT_N_SHADE_CAT; ++k) {
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(c == k);
+        if (c == k) rank[j] = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+        if (lane == 0) cnt[k][j * (PT_CLASSIFY_BLOCK / 64) + wave] = (uint32_t)__popcll(m);
+      }
+    }
+    __syncthreads();
+    if (wave < PT_N_SHADE_CAT) { /* wave k: exclusive prefix over category k's rows (64 of them), one atomic */
+      const uint32_t v = lane < kRows ? cnt[wave][lane] : 0u;
+      uint32_t incl = v;
+      for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t up = (uint32_t)__shfl_up((int)incl, off, 64);
+        if (lane >= off) incl += up;
+      }
+      const uint32_t total = (uint32_t)__shfl((int)incl, 63, 64);
+      if (lane < kRows) cnt[wave][lane] = incl - v;
+      if (lane == 0) base_of[wave] = total ? atomicAdd(lists.count + wave, total) : 0u;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < PT_CLASSIFY_ROWS; ++j) {
+      const int c = cat[j];
+      if (c < PT_N_SHADE_CAT) {
+        const unsigned long long i = base + (unsigned long long)j * PT_CLASSIFY_BLOCK + threadIdx.x;
+        lists.idx[(size_t)c * lists.cap + base_of[c] + cnt[c][j * (PT_CLASSIFY_BLOCK / 64) + wave] + rank[j]] = (uint32_t)i;
+      }
+    }
+    __syncthreads(); /* cnt / base_of are rewritten by the next iteration */
+  }
+}
+
+/* The shade stage for ONE category's list.  Same per-segment arithmetic as k_shade (pt_shade_entry); survivors are
+ * appended binned by direction octant exactly as there.  PT_CAT_MISS writes contributions only: no append, no barrier. */
+#ifndef PT_SHADE_CAT_WAVES
+#define PT_SHADE_CAT_WAVES 4
+#endif
+template <bool EMIT, bool PRIMARY, int CAT>
+__global__ __launch_bounds__(PT_SHADE_BLOCK, PT_SHADE_CAT_WAVES) void k_shade_cat(PtSceneDev sc, PtQueue q, PtHits hits, PtQueue out, PtContrib contrib,
+                                                const double* __restrict__ alpha, int bounce, int last_bounce,
+                                                PtGenParams g, PtCatLists lists, uint32_t* work) {
+  __shared__ uint32_t lds_bins[65];
+  __shared__ uint32_t lds_win[2];
+  const uint32_t n = lists.count[CAT];
+  const uint32_t* __restrict__ list = lists.idx + (size_t)CAT * lists.cap;
+  const uint32_t nc = gridDim.x < 8u ? gridDim.x : 8u, cc = blockIdx.x % nc;
+  const uint32_t total_win = (uint32_t)(((unsigned long long)n + blockDim.x - 1) / blockDim.x);
+  const uint32_t win_limit = cc < total_win ? (total_win - cc + nc - 1u) / nc : 0u; /* windows cc, cc + nc, ... */
+  if (win_limit == 0) return; /* workgroup-uniform */
+  /* windows are handed out as in k_shade: thread 0 fetches one ahead, the value is broadcast through LDS */
+  uint32_t pending = 0u;
+  if (threadIdx.x == 0) {
+    lds_win[0] = atomicAdd(work + cc, 1u);
+    pending = atomicAdd(work + cc, 1u);
+  }
+  __syncthreads();
+  uint32_t wA = lds_win[0];
+  __syncthreads();
+  for (int it = 0; wA < win_limit; ++it) {
+    if (threadIdx.x == 0) {
+      lds_win[it & 1] = pending;
+      pending = atomicAdd(work + cc, 1u);
+    }
+    const uint32_t j = (wA * nc + cc) * blockDim.x + threadIdx.x;
+    const bool live = j < n;
+    const uint32_t i = live ? list[j] : 0u;
+    PtShadeOut so;
+    pt_shade_entry<EMIT, PRIMARY, CAT>(sc, q, hits, contrib, alpha, bounce, last_bounce, g, i, live, so);
+    if (CAT != PT_CAT_MISS) {
+      const int octant = (so.n_d.x >= 0.0 ? 1 : 0) | (so.n_d.y >= 0.0 ? 2 : 0) | (so.n_d.z >= 0.0 ? 4 : 0);
+      const uint32_t dst = pt_block_append_binned<true>(out.count, so.keep, octant, lds_bins);
+      if (so.keep) {
+        out.ox[dst] = so.n_o.x; out.oy[dst] = so.n_o.y; out.oz[dst] = so.n_o.z;
+        out.dx[dst] = so.n_d.x; out.dy[dst] = so.n_d.y; out.dz[dst] = so.n_d.z;
+        out.ar[dst] = so.n_attn.x; out.ag[dst] = so.n_attn.y; out.ab[dst] = so.n_attn.z;
+        if (EMIT) { out.er[dst] = so.n_emit.x; out.eg[dst] = so.n_emit.y; out.eb[dst] = so.n_emit.z; }
+        out.id[dst] = so.id;
+        out.offset[dst] = so.offset;
+      }
+    } else {
+      __syncthreads(); /* lds_win */
+    }
+    wA = lds_win[it & 1];
+  }
 }
 
 /* ------------------------------------------------------------------ accumulate + film */
