@@ -10,6 +10,14 @@ N > 1: the SAME image, rows dealt to ranks in interleaved 8-row bands (strong sc
 point-to-point sends (RCCL over xGMI) of the raw sums into rank 0 per step; the film reads the bands in place.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with "roofline" and "cpu_baseline".
+
+Roofline.  The dominant kernel is k_trace on queued (bounce >= 1) rays.  On the headline scene the
+whole tree lives in LDS, so the kernel is bound by vector-instruction issue, not by HBM: `bound` names that pipe,
+`achieved` is the reference algorithm's floating-point work (27 flop per Bbox.is_hit, 24 per packet slot scanned, counted
+by the kernels themselves and equal to the oracle's counts) over the kernel's launch time measured live on ONE stream (so
+the per-kernel times add up to the step), `frac` <= 1 against the binary64 vector peak.  `hbm` carries the counter-measured
+traffic of the same launches (profiles/, FETCH_SIZE x 2 + WRITE_SIZE) and `issue` the tracked SQ counters (VALU busy,
+lane utilisation).  Scenes traversed from HBM/L2 (ganesha-like) report `bound: "hbm"` on algorithmic bytes instead.
 """
 import argparse
 import ctypes as C
@@ -52,6 +60,21 @@ def algorithmic_bytes(stats, spp, triangles):
     return total, trace_only
 
 
+FLOP_PER_NODE_TEST = 27.0   # Bbox.is_hit: 6 sub, 6 mul, 12 min/max, 2 clamps, 1 compare (bbox.ml:40-56)
+FLOP_PER_SLOT_SCAN = 24.0   # spheres_intersect_aux up to the discriminant (lib.rs:115-160); triangles: Moller-Trumbore ~ the same
+F64_VECTOR_PEAK_TFLOPS = 78.6  # MI355X binary64 vector peak = half the 157.3 TFLOP/s binary32 figure (MI355X_MICROARCH.md)
+
+
+def tracked_counters(workload):
+    """SQ / HBM counter summary of the dominant kernel, from the tracked rocprofv3 passes (tools/collect_profile.sh ->
+    tools/summarize_sq.py -> profiles/roofline_inputs.json).  None if this workload was never profiled."""
+    path = os.path.join(ROOT, "profiles", "roofline_inputs.json")
+    try:
+        return json.load(open(path)).get(workload)
+    except Exception:
+        return None
+
+
 def measured_hbm_copy_gbs(torch, dev):
     """Measured device copy bandwidth (read + write bytes / time) of a 1 GiB f32 tensor: the 'measured HBM
     roofline' BASELINE.md asks for next to the 8 TB/s datasheet figure."""
@@ -88,6 +111,7 @@ def cpu_baseline(workload, seconds_budget=20.0):
     """The oracle (C restatement of the reference CPU path, libm math like the OCaml runtime, tile-parallel
     over all host threads like integrator.ml:138-146) timed on a bounded sample of the same workload."""
     from oracle import oracle as O
+    flags = O.use_native_build()  # BASELINE.md section 4: -O3 -march=native on the box that runs it
     scene, w, h, spp, depth = WORKLOADS[workload]
     if scene == "shirley":
         d = O.desc_shirley(w, h)
@@ -110,8 +134,36 @@ def cpu_baseline(workload, seconds_budget=20.0):
     return {
         "value": samples / r["ms"] * 1e-3, "unit": "Msamples/s", "cores": cores, "kind": "port",
         "sample": f"{w}x{h} spp={n_pass} of {spp} depth={depth}, same scene/camera, {cores} threads, "
-                  f"{r['ms'] / 1e3:.1f} s (C restatement of the reference OCaml/Rust path, libm math)",
+                  f"{r['ms'] / 1e3:.1f} s (C restatement of the reference OCaml/Rust path, libm math, gcc {flags} -ffp-contract=off)",
+        "real_reference": real_reference(workload),
     }, r["rgb"], n_pass
+
+
+def real_reference(workload):
+    """when dune and cargo are on PATH and a checkout of the reference is at hand, also time the
+    README command (`dune exec --release shirley_spheres ...`, /root/reference/README.md:7) and call it "real
+    reference".  Neither toolchain exists in the build image or on the GPU box, so this normally reports why not."""
+    import shutil
+    import subprocess
+    scene, w, h, spp, depth = WORKLOADS[workload]
+    ref = os.environ.get("PT_REFERENCE_DIR", "/root/reference")
+    missing = [t for t in ("dune", "cargo") if shutil.which(t) is None]
+    if missing:
+        return {"value": None, "why": "not on PATH: " + ", ".join(missing)}
+    if scene != "shirley" or not os.path.isdir(ref):
+        return {"value": None, "why": "no reference checkout" if scene == "shirley" else "the reference has no path-integrator binary for this scene"}
+    cmd = ["dune", "exec", "--release", "shirley_spheres", "--", f"--dimension={w},{h}", f"--samples-per-pixel={spp}",
+           f"--max-ray-bounces={depth}", "--no-progress", "-o", "/tmp/real_reference.png"]
+    try:
+        subprocess.run(["dune", "build", "--release"], cwd=ref, check=True, capture_output=True, timeout=1800)
+        t0 = time.perf_counter()
+        out = subprocess.run(cmd, cwd=ref, check=True, capture_output=True, text=True, timeout=3600).stdout
+        wall = time.perf_counter() - t0
+        ms = [float(l.split(":")[1].split()[0]) for l in out.splitlines() if l.startswith("rendered in:")]
+        sec = ms[0] * 1e-3 if ms else wall
+        return {"value": w * h * spp / sec * 1e-6, "unit": "Msamples/s", "kind": "reference", "seconds": sec, "command": " ".join(cmd)}
+    except Exception as e:
+        return {"value": None, "why": f"{type(e).__name__}: {e}"}
 
 
 def main():
@@ -185,15 +237,28 @@ def main():
         step()
     fence()
     t0 = time.perf_counter()
-    kernel_ms = {k: 0.0 for k in ("generate", "trace", "shade", "accum", "film")}
-    launches = dict(kernel_ms)
     for _ in range(args.steps):
-        st = step()
-        for k in kernel_ms:
-            kernel_ms[k] += st["kernel_ms"][k]
-            launches[k] += st["kernel_launches"][k]
+        step()
     fence()
     elapsed = time.perf_counter() - t0
+    # untimed: the same step on ONE stream with every launch bracketed by HIP events on the launch stream, so that the
+    # per-kernel durations are not inflated by a co-scheduled batch and add up to (at most) the step
+    tparams = P.render_params(w, h, spp, depth, band_rows=D.BAND_ROWS, band_first=rank, band_step=world,
+                              time_kernels=True, passes_per_batch=args.passes_per_batch)
+    prev_streams = os.environ.get("PTX_STREAMS")
+    os.environ["PTX_STREAMS"] = "1"
+    try:
+        scene.render_raw_device(tparams, part.data_ptr(), stream)  # warm
+        t1 = time.perf_counter()
+        st1 = scene.render_raw_device(tparams, part.data_ptr(), stream)
+        one_stream_ms = (time.perf_counter() - t1) * 1e3
+    finally:
+        if prev_streams is None:
+            del os.environ["PTX_STREAMS"]
+        else:
+            os.environ["PTX_STREAMS"] = prev_streams
+    kernel_ms = {k: st1["kernel_ms"][k] for k in ("generate", "trace", "shade", "accum", "film")}
+    launches = {k: st1["kernel_launches"][k] for k in kernel_ms}
     cdev = dev if args.backend == "nccl" else torch.device("cpu")  # where the tiny control tensors live
     t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
     if world > 1:
@@ -214,27 +279,63 @@ def main():
         dist.all_reduce(mx, op=dist.ReduceOp.MAX)
         cvec = torch.cat([summed[:5], mx[5:]])
     counts = dict(zip(keys, [int(v) for v in cvec[:5].tolist()]))
-    trace_ms_total, trace_launches = float(cvec[5]), float(cvec[6])
+    trace_ms_total, trace_launches = float(cvec[5]), float(cvec[6])  # one step, one stream
 
     if rank == 0:
         samples = w * h * spp
         ms_per_step = elapsed / args.steps * 1e3
         value = samples * args.steps / elapsed * 1e-6
         b_total, b_trace = algorithmic_bytes(counts, spp, scene_name != "shirley")
-        # dominant kernel = trace: algorithmic bytes of one step's trace launches / their summed HIP-event time
-        trace_ms_step = trace_ms_total / args.steps
-        achieved = b_trace / (trace_ms_step * 1e-3) * 1e-9 if trace_ms_step > 0 else 0.0
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath):
-            try:
-                traffic = json.load(open(tpath)).get(args.workload, {}).get("trace_hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
+        # dominant kernel = trace: algorithmic work of one step's trace launches / their summed HIP-event time (one stream)
+        trace_ms_step = trace_ms_total
+        n_launch = max(trace_launches, 1.0)
+        avg_launch_s = trace_ms_step * 1e-3 / n_launch
+        in_lds = bool(sstats["traversal_in_lds"])
+        tc = tracked_counters(args.workload) or {}
+        traffic = tc.get("trace_hbm_bytes_per_launch")
         try:
             copy_gbs = measured_hbm_copy_gbs(torch, dev)
         except Exception:
             copy_gbs = None
+        alg_flop = counts["nodes_tested"] * FLOP_PER_NODE_TEST + (counts["prims_tested"] + counts["floor_tested"]) * FLOP_PER_SLOT_SCAN
+        flops_achieved = alg_flop / (trace_ms_step * 1e-3) * 1e-12 if trace_ms_step > 0 else 0.0
+        bytes_achieved = b_trace / (trace_ms_step * 1e-3) * 1e-9 if trace_ms_step > 0 else 0.0
+        hbm_block = {"traffic": traffic, "achieved": (traffic / avg_launch_s * 1e-9) if (traffic and avg_launch_s > 0) else None,
+                     "peak": HBM_PEAK_GBS * world, "unit": "GB/s", "peak_measured_copy": copy_gbs,
+                     "source": tc.get("source", "not profiled"),
+                     "note": "HBM bytes per k_trace launch from rocprofv3 counters (2 x FETCH_SIZE + WRITE_SIZE), over the live launch duration"}
+        hbm_block["frac"] = (hbm_block["achieved"] / hbm_block["peak"]) if hbm_block["achieved"] else None
+        if in_lds:
+            # tree + packets are LDS-resident: node / slot reads never reach HBM, the binding pipe is vector issue
+            roofline = {"bound": "valu_f64", "kernel": "k_trace", "achieved": flops_achieved, "peak": F64_VECTOR_PEAK_TFLOPS * world,
+                        "unit": "TFLOP/s", "frac": flops_achieved / (F64_VECTOR_PEAK_TFLOPS * world), "traffic": traffic,
+                        "algorithmic_flop_per_launch": alg_flop / n_launch,
+                        "flop_model": f"{FLOP_PER_NODE_TEST:g} per Bbox.is_hit + {FLOP_PER_SLOT_SCAN:g} per packet slot scanned (reference arithmetic, binary64)",
+                        "issue": {k: tc.get(k) for k in ("valu_busy", "lane_util", "useful_issue_frac", "lds_busy", "lds_bank_conflict_share", "source")},
+                        "hbm": hbm_block}
+        else:
+            roofline = {"bound": "hbm", "kernel": "k_trace / k_trace_stream", "achieved": bytes_achieved, "peak": HBM_PEAK_GBS * world,
+                        "unit": "GB/s", "frac": bytes_achieved / (HBM_PEAK_GBS * world), "traffic": traffic,
+                        "algorithmic_bytes_per_launch": b_trace / n_launch,
+                        "served_from": "l1/l2/infinity cache/hbm (the tree is larger than LDS)",
+                        "issue": {k: tc.get(k) for k in ("valu_busy", "lane_util", "useful_issue_frac", "source")},
+                        "hbm": hbm_block}
+            if roofline["frac"] > 1.0:  # algorithmic bytes served from cache: say so instead of claiming > 100 % of HBM
+                roofline["note"] = "algorithmic bytes exceed what HBM could deliver: node re-reads are served by L2 / Infinity Cache; see hbm.traffic"
+        roofline.update({"launches_per_step": n_launch, "avg_launch_ms": trace_ms_step / n_launch,
+                         "timing": "HIP events on the launch stream, one-stream pass (PTX_STREAMS=1)",
+                         "pipeline": {"bytes_per_sample": b_total / samples, "achieved": b_total * args.steps / elapsed * 1e-9,
+                                      "unit": "GB/s (algorithmic, SURVEY section 8 D)"}})
+        # the host-framebuffer entry point the CLI and the OCaml stub call (one 24 B/pixel device-to-host copy more)
+        try:
+            scene.render(w, h, spp, depth)
+            t2 = time.perf_counter()
+            scene.render(w, h, spp, depth)
+            host_ms = (time.perf_counter() - t2) * 1e3
+            host_api = {"ptx_render_ms": host_ms, "msamples_per_s": samples / host_ms * 1e-3,
+                        "note": "ptx_render: whole frame on this GPU, post-gamma framebuffer copied to host memory"} if world == 1 else None
+        except Exception as e:
+            host_api = {"ptx_render_ms": None, "note": f"unavailable: {e}"}
         out = {
             "metric": "Msamples/s (WxHxspp) + achieved HBM GB/s vs roofline; per-pixel Linf vs CPU ref",
             "value": value, "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -244,27 +345,9 @@ def main():
                        "max_bounces": depth, "samples_per_step": samples,
                        "sharding": f"{world} rank(s), interleaved {D.BAND_ROWS}-row bands, 1 gather/step" if world > 1 else "1 rank",
                        "tree_nodes": sstats["tree_nodes"], "tree_depth": sstats["tree_depth"], "leaf_slots": sstats["leaf_slots"]},
-            "roofline": {
-                # N ranks: whole-job bytes over the slowest rank's kernel time, against N GPUs' HBM
-                "bound": "hbm", "kernel": "k_trace", "achieved": achieved, "peak": HBM_PEAK_GBS * world, "unit": "GB/s",
-                "frac": achieved / (HBM_PEAK_GBS * world), "traffic": traffic,
-                "peak_measured_copy": copy_gbs, "frac_of_measured": (achieved / (copy_gbs * world)) if copy_gbs else None,
-                "algorithmic_bytes_per_launch": b_trace / max(trace_launches / args.steps, 1.0),
-                "launches_per_step": trace_launches / args.steps, "avg_launch_ms": trace_ms_total / max(trace_launches, 1.0),
-                # where the algorithmic bytes are actually served from: small scenes are copied to LDS once per workgroup,
-                # so node / packet reads never reach HBM (that is how `frac` can exceed 1; `traffic` is the HBM truth)
-                "served_from": "lds" if sstats["traversal_in_lds"] else "l1/l2/hbm",
-                "pipeline": {"bytes_per_sample": b_total / samples, "achieved": b_total * args.steps / elapsed * 1e-9,
-                             "frac": b_total * args.steps / elapsed * 1e-9 / (HBM_PEAK_GBS * world)},
-                # the kernel's real ceiling: f64 vector issue.  27 flop per node test (6 sub, 6 mul, 12 min/max,
-                # 2 clamps, 1 compare), 24 per packet slot (scan part), against 78.6 TFLOP/s f64 vector peak
-                **({"lds": {"achieved": achieved, "peak": 256 * 128 * 2.4 * world, "unit": "GB/s",
-                            "frac": achieved / (256 * 128 * 2.4 * world), "note": "256 CUs x 128 B/clk (8-byte reads) x 2.4 GHz"}}
-                   if sstats["traversal_in_lds"] else {}),
-                "valu_f64": {"achieved_tflops": (counts["nodes_tested"] * 27.0 + counts["prims_tested"] * 24.0) / (trace_ms_step * 1e-3) * 1e-12 if trace_ms_step > 0 else 0.0,
-                             "peak_tflops": 78.6 * world},
-            },
-            "kernel_ms_per_step": {k: v / args.steps for k, v in kernel_ms.items()},
+            "roofline": roofline,
+            "kernel_ms_per_step": dict(kernel_ms, one_stream_step_ms=one_stream_ms),
+            "host_api": host_api,
             "work": {**counts, "segments_per_sample": counts["segments"] / samples,
                      "nodes_per_segment": counts["nodes_tested"] / max(counts["segments"], 1),
                      "prims_per_segment": counts["prims_tested"] / max(counts["segments"], 1)},

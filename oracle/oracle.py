@@ -29,11 +29,35 @@ def build(force=False):
     return so
 
 
+_SO_OVERRIDE = None
+
+
+def use_native_build():
+    """bench.py's cpu_baseline leg: (re)build the oracle ON THIS MACHINE with the flags BASELINE.md section 4 states
+    (-O3 -march=native -ffp-contract=off) into oracle/_native/ and make lib() load that copy.  The shipped
+    libpt_oracle.so is -O2 -march=x86-64-v3 because it is built in one container and run in another.  Same C source,
+    contraction off in both: the results are bit-identical, only the speed differs.  Returns the flags actually used."""
+    global _SO_OVERRIDE, _LIB
+    if _LIB is not None:
+        return "-O2 -march=x86-64-v3 (already loaded)"
+    out_dir = os.path.join(_HERE, "_native")
+    so = os.path.join(out_dir, "libpt_oracle_native.so")
+    flags = ["-O3", "-march=native", "-ffp-contract=off", "-fno-math-errno", "-fno-fast-math", "-fPIC", "-std=gnu11", "-fvisibility=hidden"]
+    try:
+        os.makedirs(out_dir, exist_ok=True)
+        subprocess.check_call(["gcc", *flags, "-shared", "-o", so, os.path.join(_HERE, "pt_oracle.c"), "-lm", "-lpthread"],
+                              stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=300)
+        _SO_OVERRIDE = so
+        return "-O3 -march=native"
+    except Exception:
+        return "-O2 -march=x86-64-v3 (native rebuild failed)"
+
+
 def lib():
     global _LIB
     if _LIB is not None:
         return _LIB
-    so = build()
+    so = _SO_OVERRIDE or build()
     L = C.CDLL(so)
     L.orc_math.restype = C.c_double
     L.orc_math.argtypes = [C.c_int, C.c_double, C.c_double]

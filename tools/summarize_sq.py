@@ -1,21 +1,28 @@
 #!/usr/bin/env python3
-"""Per-kernel summary of the SQ / HBM counter passes of tools/collect_profile.sh -> profiles/<tag>_sq.json.
-usage: tools/summarize_sq.py gpurun_out/r02a_shirley r02 [workload]
+"""Per-kernel summary of the rocprofv3 passes of tools/collect_profile.sh -> profiles/<tag>_sq.json,
+profiles/<tag>_kernel_stats.csv (two-stream frame), profiles/<tag>_kernel_stats_one_stream.csv, and the entry of
+profiles/roofline_inputs.json that bench.py reads for its `roofline.issue` / `roofline.hbm` blocks.
+usage: tools/summarize_sq.py gpurun_out/r02_shirley r02 shirley_1080p_spp64_d8
 
-Derived figures (MI355X_MICROARCH.md, rocprofv3 PMC section; SQ_*_CYCLES and SQ_ACTIVE_INST_* count quad-cycles):
-  lane_util      = SQ_THREAD_CYCLES_VALU / (SQ_ACTIVE_INST_VALU * 64)   active lanes per issued VALU instruction
-  valu_busy      = SQ_ACTIVE_INST_VALU * 4 / (SQ_BUSY_CYCLES_per_SIMD)   share of time the vector pipes issue (per SIMD)
-  valu_of_wave   = SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES                 share of a resident wave's life spent issuing VALU
-  lds_of_wave    = SQ_ACTIVE_INST_LDS / SQ_WAVE_CYCLES
-  bank_conflict  = SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE             LDS-array cycles that are conflict replays
-  wait_any / wait_inst_any = SQ_WAIT_* / SQ_WAVE_CYCLES                 parked on s_waitcnt / stalled at issue
-  hbm_bytes      = 2 * FETCH_SIZE + WRITE_SIZE (KB -> bytes; the gfx950 x2 correction for wide coalesced reads)
+Derived figures (MI355X_MICROARCH.md, "rocprofv3 PMC slots": SQ_*_CYCLES and SQ_ACTIVE_INST_* count quad-cycles;
+SQ_BUSY_CYCLES counts cycles once per shader engine, 32 of them):
+  cycles          = SQ_BUSY_CYCLES / 32                                kernel duration in shader cycles, summed over launches
+  valu_busy       = 4 SQ_ACTIVE_INST_VALU / (1024 SIMDs x cycles)      share of SIMD time the vector pipe issues
+  lane_util       = SQ_THREAD_CYCLES_VALU / (64 SQ_ACTIVE_INST_VALU)   active lanes per issued vector instruction
+  useful_issue_frac = valu_busy x lane_util                            useful lane-issue slots / all lane-issue slots
+  lds_busy        = SQ_LDS_IDX_ACTIVE / (256 CUs x cycles)   (LDS-array cycles; scaled between passes by SQ_WAVE_CYCLES)
+  lds_bank_conflict_share = SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE
+  wait_any / wait_inst_any / active_inst_any = SQ_* / SQ_WAVE_CYCLES   parked on s_waitcnt or a barrier / stalled at issue / issuing
+  wave_residency  = 4 SQ_WAVE_CYCLES / (SQ_WAVES x cycles)             share of the kernel's duration an average wave is alive
+  hbm_bytes_per_launch = (2 FETCH_SIZE + WRITE_SIZE) KB                the gfx950 x2 correction for wide coalesced reads
 """
-import collections, csv, glob, json, os, sys
+import collections, csv, glob, json, os, shutil, sys
 
 src, tag = sys.argv[1], sys.argv[2]
 workload = sys.argv[3] if len(sys.argv) > 3 else "shirley_1080p_spp64_d8"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+prof = os.path.join(root, "profiles")
+os.makedirs(prof, exist_ok=True)
 
 
 def newest(pattern):
@@ -24,63 +31,110 @@ def newest(pattern):
 
 
 def short(name):
-    k = name.split("(")[0].replace("void ", "").strip()
-    return k
+    return name.split("(")[0].replace("void ", "").strip()
 
 
-agg = collections.defaultdict(lambda: collections.defaultdict(float))
-launches = collections.defaultdict(lambda: collections.Counter())
+passes = {}
 for sub in ("sq_a", "sq_b", "sq_c", "pmc_fetch", "pmc_write"):
     f = newest(os.path.join(src, sub, "*", "*counter_collection.csv"))
     if not f:
         continue
+    agg = collections.defaultdict(lambda: collections.defaultdict(float))
+    n = collections.defaultdict(collections.Counter)
     for r in csv.DictReader(open(f)):
         k = short(r["Kernel_Name"])
-        if not k.startswith("k_"):
-            continue
-        agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
-        launches[k][r["Counter_Name"]] += 1
+        if k.startswith("k_"):
+            agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
+            n[k][r["Counter_Name"]] += 1
+    passes[sub] = (agg, n)
 
 dur = {}
-f = newest(os.path.join(src, "ktrace1", "*", "*kernel_stats.csv"))
-if f:
-    for r in csv.DictReader(open(f)):
-        dur[short(r["Name"])] = {"calls": int(r["Calls"]), "avg_us": float(r["AverageNs"]) / 1e3, "total_ms": float(r["TotalDurationNs"]) / 1e6}
+for sub, dst in (("ktrace1", f"{tag}_kernel_stats_one_stream.csv"), ("ktrace", f"{tag}_kernel_stats.csv")):
+    f = newest(os.path.join(src, sub, "*", "*kernel_stats.csv"))
+    if f:
+        shutil.copy(f, os.path.join(prof, dst))
+        if sub == "ktrace1":
+            for r in csv.DictReader(open(f)):
+                dur[short(r["Name"])] = {"calls": int(r["Calls"]), "avg_us": float(r["AverageNs"]) / 1e3, "total_ms": float(r["TotalDurationNs"]) / 1e6}
+line = [l for l in open(os.path.join(src, "bench_ktrace.log")) if l.startswith("{")] if os.path.exists(os.path.join(src, "bench_ktrace.log")) else []
+if line:
+    open(os.path.join(prof, f"{tag}_bench_under_rocprof.json"), "w").write(line[-1])
 
-out = {"workload": workload, "source": src, "note": "bench.py --steps 2 --warmup 1 under rocprofv3, PTX_STREAMS=1 for the counter and ktrace1 passes", "kernels": {}}
-for k, c in sorted(agg.items()):
-    n = max(launches[k].values())
-    e = {"launches": n, "counters_sum": {m: v for m, v in sorted(c.items())}}
-    g = c.get
-    if g("SQ_ACTIVE_INST_VALU"):
-        e["lane_util"] = g("SQ_THREAD_CYCLES_VALU", 0) / (g("SQ_ACTIVE_INST_VALU") * 64)
-    if g("SQ_WAVE_CYCLES"):
-        wc = g("SQ_WAVE_CYCLES")
-        # sq_a and sq_b both carry SQ_WAVE_CYCLES (summed twice): normalise by the number of passes that had it
-        passes = launches[k]["SQ_WAVE_CYCLES"] / max(launches[k].get("SQ_ACTIVE_INST_VALU", n), 1)
-        wc1 = wc / max(passes, 1)
-        e["valu_of_wave"] = g("SQ_ACTIVE_INST_VALU", 0) / wc1
-        e["lds_of_wave"] = g("SQ_ACTIVE_INST_LDS", 0) / wc1
-        e["wait_any"] = g("SQ_WAIT_ANY", 0) / wc1
-        e["wait_inst_any"] = g("SQ_WAIT_INST_ANY", 0) / wc1
-        e["active_inst_any"] = g("SQ_ACTIVE_INST_ANY", 0) / wc1
-    if g("SQ_BUSY_CYCLES"):
-        e["valu_busy"] = g("SQ_ACTIVE_INST_VALU", 0) * 4 / g("SQ_BUSY_CYCLES") if g("SQ_BUSY_CYCLES") else None
-    if g("SQ_LDS_IDX_ACTIVE"):
-        e["lds_bank_conflict_share"] = g("SQ_LDS_BANK_CONFLICT", 0) / g("SQ_LDS_IDX_ACTIVE")
-    if g("SQ_INSTS_VALU") and g("SQ_WAVES"):
-        e["valu_insts_per_wave"] = g("SQ_INSTS_VALU") / g("SQ_WAVES")
-    if "FETCH_SIZE" in c or "WRITE_SIZE" in c:
-        e["hbm_bytes_per_launch"] = (2.0 * g("FETCH_SIZE", 0) + g("WRITE_SIZE", 0)) * 1024.0 / n
+
+def val(sub, k, name):
+    if sub not in passes:
+        return None, 0
+    agg, n = passes[sub]
+    return (agg[k].get(name), n[k].get(name, 0)) if k in agg else (None, 0)
+
+
+kernels = sorted({k for agg, _ in passes.values() for k in agg})
+out = {"workload": workload, "source": src,
+       "note": "bench.py --steps 2 --warmup 1 under rocprofv3; PTX_STREAMS=1 for the counter passes and ktrace1", "kernels": {}}
+for k in kernels:
+    e = {}
+    g = lambda name, sub: val(sub, k, name)[0]
+    busy, nl = val("sq_a", k, "SQ_BUSY_CYCLES")
+    e["launches"] = nl
+    if busy:
+        cycles = busy / 32.0
+        av, tc, waves, wca = g("SQ_ACTIVE_INST_VALU", "sq_a"), g("SQ_THREAD_CYCLES_VALU", "sq_a"), g("SQ_WAVES", "sq_a"), g("SQ_WAVE_CYCLES", "sq_a")
+        e["valu_busy"] = 4.0 * av / (1024.0 * cycles)
+        e["lane_util"] = tc / (64.0 * av)
+        e["useful_issue_frac"] = e["valu_busy"] * e["lane_util"]
+        e["valu_insts_per_launch"] = g("SQ_INSTS_VALU", "sq_a") / nl
+        e["lds_insts_per_launch"] = g("SQ_INSTS_LDS", "sq_a") / nl
+        e["wave_residency"] = 4.0 * wca / (waves * cycles / nl) if waves else None
+        e["waves_per_launch"] = waves / nl
+        wcb = g("SQ_WAVE_CYCLES", "sq_b")
+        if wcb:
+            scale = wca / wcb
+            e["lds_busy"] = g("SQ_LDS_IDX_ACTIVE", "sq_b") * scale / (256.0 * cycles)
+            idx = g("SQ_LDS_IDX_ACTIVE", "sq_b")
+            e["lds_bank_conflict_share"] = g("SQ_LDS_BANK_CONFLICT", "sq_b") / idx if idx else 0.0
+            e["wait_any"] = g("SQ_WAIT_ANY", "sq_b") / wcb
+            e["wait_inst_any"] = g("SQ_WAIT_INST_ANY", "sq_b") / wcb
+            e["active_inst_any"] = g("SQ_ACTIVE_INST_ANY", "sq_b") / wcb
+            e["salu_insts_per_launch"] = g("SQ_INSTS_SALU", "sq_b") / val("sq_b", k, "SQ_INSTS_SALU")[1]
+    f, nf = val("pmc_fetch", k, "FETCH_SIZE")
+    w, nw = val("pmc_write", k, "WRITE_SIZE")
+    if f is not None and w is not None and nf and nw:
+        e["hbm_fetch_bytes_per_launch_x2_corrected"] = 2.0 * f * 1024.0 / nf
+        e["hbm_write_bytes_per_launch"] = w * 1024.0 / nw
+        e["hbm_bytes_per_launch"] = e["hbm_fetch_bytes_per_launch_x2_corrected"] + e["hbm_write_bytes_per_launch"]
     if k in dur:
         e["one_stream"] = dur[k]
         if "hbm_bytes_per_launch" in e:
             e["hbm_gbs"] = e["hbm_bytes_per_launch"] / (dur[k]["avg_us"] * 1e-6) * 1e-9
             e["hbm_frac_of_8tbs"] = e["hbm_gbs"] / 8000.0
     out["kernels"][k] = e
-dst = os.path.join(root, "profiles", f"{tag}_sq.json")
-json.dump(out, open(dst, "w"), indent=1)
+json.dump(out, open(os.path.join(prof, f"{tag}_sq.json"), "w"), indent=1)
+
+
+# ---- the dominant kernel's entry for bench.py: k_trace / k_trace_stream instantiations with COUNT = false
+def is_timed_trace(k):
+    if not k.startswith(("k_trace<", "k_trace_stream<")):
+        return False
+    targs = [t.strip() for t in k[k.index("<") + 1:k.rindex(">")].split(",")]
+    return targs[1] == "false"
+
+
+tr = {k: e for k, e in out["kernels"].items() if is_timed_trace(k) and e.get("launches")}
+sec = {k: e for k, e in tr.items() if k.startswith("k_trace_stream<") or [t.strip() for t in k[k.index("<") + 1:k.rindex(">")].split(",")][2] == "false"}
+ri_path = os.path.join(prof, "roofline_inputs.json")
+ri = json.load(open(ri_path)) if os.path.exists(ri_path) else {}
+if tr:
+    nl = sum(e["launches"] for e in tr.values())
+    entry = {"source": f"profiles/{tag}_sq.json",
+             "trace_hbm_bytes_per_launch": sum(e.get("hbm_bytes_per_launch", 0.0) * e["launches"] for e in tr.values()) / nl,
+             "trace_avg_launch_us_one_stream": sum(e["one_stream"]["avg_us"] * e["one_stream"]["calls"] for e in tr.values() if "one_stream" in e)
+                                               / max(sum(e["one_stream"]["calls"] for e in tr.values() if "one_stream" in e), 1)}
+    dom = max(sec.values(), key=lambda e: e["launches"]) if sec else max(tr.values(), key=lambda e: e["launches"])
+    for key in ("valu_busy", "lane_util", "useful_issue_frac", "lds_busy", "lds_bank_conflict_share", "wait_any", "wait_inst_any", "wave_residency"):
+        entry[key] = dom.get(key)
+    entry["counters_of"] = [k for k, e in out["kernels"].items() if e is dom][0]
+    ri[workload] = entry
+    json.dump(ri, open(ri_path, "w"), indent=1)
+    print(json.dumps(entry, indent=1))
 for k, e in out["kernels"].items():
-    print(k)
-    print("   ", {m: (round(v, 4) if isinstance(v, float) else v) for m, v in e.items() if m not in ("counters_sum",)})
-print("wrote", dst)
+    print(k, {m: (round(v, 4) if isinstance(v, float) else v) for m, v in e.items() if m != "one_stream"}, e.get("one_stream"))
