@@ -44,7 +44,7 @@ def lib():
         L.pth_ply_floats.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p]
         L.pth_ply_ints.restype = C.POINTER(C.c_int64)
         L.pth_ply_ints.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p]
-        L.pth_ply_rows.restype = abi.c_int32_p
+        L.pth_ply_rows.restype = C.POINTER(C.c_int64)
         L.pth_ply_rows.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(abi.c_int32_p)]
         L.pth_scene_ganesha_ply.restype = C.c_void_p
         L.pth_scene_ganesha_ply.argtypes = [C.c_char_p, C.c_int32, C.c_int32]

@@ -43,7 +43,7 @@ void pth_ply_free(pth_ply* p);
 int64_t pth_ply_count(const pth_ply* p, const char* key);
 const double* pth_ply_floats(const pth_ply* p, const char* element, const char* property);  /* Column.Floats */
 const int64_t* pth_ply_ints(const pth_ply* p, const char* element, const char* property);   /* Column.Ints */
-const int32_t* pth_ply_rows(pth_ply* p, const char* list_property, const int32_t** lengths_out); /* Column.Rows, flattened */
+const int64_t* pth_ply_rows(pth_ply* p, const char* list_property, const int32_t** lengths_out); /* Column.Rows, flattened */
 /* ganesha/bin/main.ml with -ganesha-ply PATH: Mesh.create + floor + camera; sky background (extension) */
 pth_scene* pth_scene_ganesha_ply(const char* path, int32_t width, int32_t height);
 /* the synthetic stand-in mesh written as a PLY file with the real model's layout */

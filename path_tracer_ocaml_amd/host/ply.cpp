@@ -103,9 +103,10 @@ bool starts_with(const std::string& s, const char* p) { return s.rfind(p, 0) == 
 struct pth_ply {
   std::map<std::string, std::map<std::string, std::vector<double>>> floats; // element -> property -> column
   std::map<std::string, std::map<std::string, std::vector<int64_t>>> ints;
-  std::map<std::string, std::vector<std::vector<int32_t>>> rows;          // list PROPERTY name -> rows
+  std::map<std::string, std::vector<std::vector<int64_t>>> rows;          // list PROPERTY name -> rows (OCaml ints: a uint above 2^31 stays positive)
   std::map<std::string, long long> counts;
-  std::vector<int32_t> flat_rows, row_lengths; // last accessed list, flattened for the C interface
+  std::vector<int64_t> flat_rows;   // last accessed list, flattened for the C interface
+  std::vector<int32_t> row_lengths;
 };
 
 extern "C" {
@@ -249,7 +250,7 @@ static pth_ply* ply_load_impl(const char* path) {
       if (ply->rows.count(p.name) || ply->counts.count(p.name)) return fail("duplicate key " + p.name); // Map.of_alist_exn
       if (ei + 1 != elements.size()) return fail("a list element must be the last element (the reference's list reader does not advance its input, ply.ml:219-235)");
       if ((size_t)e.count > (buf.size() - pos) / (type_size(p.length_type) ? type_size(p.length_type) : 1)) return fail("truncated list element " + e.name);
-      std::vector<std::vector<int32_t>> rows((size_t)e.count);
+      std::vector<std::vector<int64_t>> rows((size_t)e.count);
       const size_t ls = type_size(p.length_type), es = type_size(p.type);
       for (long long i = 0; i < e.count; ++i) {
         if (pos + ls > buf.size()) return fail("truncated list element " + e.name);
@@ -257,7 +258,7 @@ static pth_ply* ply_load_impl(const char* path) {
         pos += ls;
         if (len < 0 || pos + (size_t)len * es > buf.size()) return fail("truncated list element " + e.name);
         rows[(size_t)i].resize((size_t)len);
-        for (int64_t k = 0; k < len; ++k) rows[(size_t)i][(size_t)k] = (int32_t)read_int(&buf[pos + (size_t)k * es], p.type);
+        for (int64_t k = 0; k < len; ++k) rows[(size_t)i][(size_t)k] = read_int(&buf[pos + (size_t)k * es], p.type);
         pos += (size_t)len * es;
       }
       ply->rows[p.name] = std::move(rows);
@@ -317,7 +318,7 @@ const int64_t* pth_ply_ints(const pth_ply* p, const char* element, const char* p
 }
 
 // rows of list property `name`: lengths_out[i] = row length, returns the flattened values (or NULL)
-const int32_t* pth_ply_rows(pth_ply* p, const char* name, const int32_t** lengths_out) {
+const int64_t* pth_ply_rows(pth_ply* p, const char* name, const int32_t** lengths_out) {
   if (!p) return nullptr;
   auto it = p->rows.find(name);
   if (it == p->rows.end()) return nullptr;
@@ -357,10 +358,10 @@ extern "C" pth_scene* pth_scene_ganesha_ply(const char* path, int32_t width, int
   tri.reserve(rows->second.size() * 3);
   const int32_t nv = (int32_t)x.size();
   for (const auto& r : rows->second) {
-    for (int32_t a : r)
+    for (int64_t a : r)
       if (a < 0 || a >= nv) return bail("face index out of bounds"); // assert (Array.for_all faces ~f:in_bounds)
     if (r.size() != 3) return bail("expected triangular face");      // main.ml:182-185
-    tri.insert(tri.end(), r.begin(), r.end());
+    for (int64_t a : r) tri.push_back((int32_t)a);
   }
   if (tri.empty()) return bail("Shape_tree.create: expected non-empty list of shapes");
   pth_scene* s = pth_scene_ganesha_from_mesh(width, height, x, y, z, tri, true);

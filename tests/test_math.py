@@ -1,0 +1,53 @@
+"""Accuracy of csrc/pt_math.h (the shared host / device math the product and the oracle's math mode 0 both use) against
+mpmath at 60 digits: the claim in pt_math.h's header.  The functions are exercised through the oracle's host build; the
+device build is bit-identical to it (tests/test_gpu_parity.py::test_math_device_equals_host_bitwise)."""
+import math
+
+import numpy as np
+import pytest
+
+mp = pytest.importorskip("mpmath")
+mp.mp.dps = 60
+
+FN = {"hypot": 0, "sin": 1, "cos": 2, "acos": 3, "atan2": 4, "pow5": 5}
+
+
+def ulp_errors(got, exact):
+    """|got - exact| in units of the last place of the exact value's binade"""
+    out = []
+    for g, e in zip(got, exact):
+        if e == 0:
+            out.append(0.0 if g == 0 else float("inf"))
+            continue
+        ulp = mp.mpf(2) ** (mp.floor(mp.log(abs(e), 2)) - 52)
+        out.append(float(abs(mp.mpf(float(g)) - e) / ulp))
+    return np.array(out)
+
+
+@pytest.mark.parametrize("fn,bound", [("hypot", 1.0), ("sin", 1.0), ("cos", 1.0), ("acos", 1.0), ("atan2", 1.5), ("pow5", 0.5000001)])
+def test_pt_math_accuracy_vs_mpmath(oracle, fn, bound):
+    rng = np.random.default_rng(100 + FN[fn])
+    n = 6000
+    b = None
+    if fn == "hypot":  # V3.normalize / Quaternion.normalize: components of unit-ish vectors and scene-scale offsets
+        a = rng.uniform(-4, 4, n) * 10.0 ** rng.integers(-3, 4, n)
+        b = rng.uniform(-4, 4, n) * 10.0 ** rng.integers(-3, 4, n)
+        exact = [mp.sqrt(mp.mpf(float(x)) ** 2 + mp.mpf(float(y)) ** 2) for x, y in zip(a, b)]
+    elif fn in ("sin", "cos"):  # theta = v * 2 * pi, v in [0, 1)  (shader_space.ml:56-64)
+        a = np.concatenate([rng.uniform(0, 2 * math.pi, n - 200), rng.uniform(-50, 50, 200)])
+        f = mp.sin if fn == "sin" else mp.cos
+        exact = [f(mp.mpf(float(x))) for x in a]
+    elif fn == "acos":  # acos (-n.y), |n| = 1  (sphere.ml:25-33)
+        a = np.concatenate([rng.uniform(-1, 1, n - 4), [1.0, -1.0, 0.0, 0.999999999]])
+        exact = [mp.acos(mp.mpf(float(x))) for x in a]
+    elif fn == "atan2":  # atan2 (-n.z) n.x
+        a = rng.uniform(-1, 1, n)
+        b = rng.uniform(-1, 1, n)
+        exact = [mp.atan2(mp.mpf(float(y)), mp.mpf(float(x))) for y, x in zip(a, b)]
+    else:  # (1 - cos) ** 5.0, 1 - cos in [0, 1]  (material.ml:16-20,37)
+        a = np.concatenate([rng.uniform(0, 1, n - 500), rng.uniform(-2, 2, 500)])
+        exact = [mp.mpf(float(x)) ** 5 for x in a]
+    got = oracle.math_vec(FN[fn], a, b)
+    err = ulp_errors(got, exact)
+    assert np.isfinite(err).all()
+    assert err.max() <= bound, f"{fn}: max error {err.max():.3f} ulp (bound {bound}) at input {a[int(err.argmax())]!r}"

@@ -30,6 +30,150 @@ def H():
     return host
 
 
+@pytest.fixture
+def PO():
+    from oracle import ply_oracle  # the restatement of ply.ml: the checker, never the product
+    return ply_oracle
+
+
+_PY2PLY = {"f": "float", "d": "double", "b": "char", "B": "uchar", "h": "short", "H": "ushort", "i": "int", "I": "uint"}
+
+
+def _compare(H, PO, path):
+    """every column / row list the oracle returns, against the product's reader"""
+    want = PO.of_file(path)
+    ply = H.Ply(path)
+    for key, cols in want.items():
+        if "rows" in cols:
+            assert ply.count(key) == len(cols["rows"])
+            assert [list(r) for r in ply.rows(key)] == cols["rows"], key
+            continue
+        for name, (kind, values) in cols.items():
+            assert ply.count(key) == len(values)
+            if kind == "floats":
+                got = ply.floats(key, name)
+                assert got is not None and np.array_equal(np.asarray(got).view(np.uint64), np.asarray(values, dtype=np.float64).view(np.uint64)), (key, name)
+                assert ply.ints(key, name) is None
+            else:
+                got = ply.ints(key, name)
+                assert got is not None and list(got) == values, (key, name)
+    return want
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_product_reader_equals_the_ply_ml_restatement_on_generated_files(H, PO, tmp_path, seed):
+    """Random headers over every type ply.ml knows EXCEPT the 16-bit ones (their quirk has its own test): several scalar
+    elements with mixed float / integer columns, comments, alias type names, then one list element (last)."""
+    rng = np.random.default_rng(seed)
+    header, payload = ["format binary_little_endian 1.0", "comment generated", "obj_info seed %d" % seed], b""
+    codes = "fdbBiI"
+    alias = {"B": ["uchar", "uint8", "Uchar"], "b": ["char", "int8", "Char"], "f": ["float", "Float"], "d": ["double", "Double"],
+             "i": ["int", "Int"], "I": ["uint", "Uint"]}
+    for e in range(int(rng.integers(1, 4))):
+        n, k = int(rng.integers(0, 40)), int(rng.integers(1, 6))
+        tys = [codes[int(rng.integers(0, len(codes)))] for _ in range(k)]
+        header.append(f"element elt{e} {n}" if rng.random() < 0.8 else f"element elt{e} {n:_}")
+        for j, t in enumerate(tys):
+            names = alias[t]
+            header.append(f"property {names[int(rng.integers(0, len(names)))]} p{j}")
+        for _ in range(n):
+            for t in tys:
+                if t in "fd":
+                    payload += struct.pack("<" + t, float(rng.normal()) * 10.0 ** int(rng.integers(-3, 4)))
+                else:
+                    lo, hi = {"b": (-128, 128), "B": (0, 256), "i": (-2**31, 2**31), "I": (0, 2**32)}[t]
+                    payload += struct.pack("<" + t, int(rng.integers(lo, hi)))
+    lt, et = "BbiI"[int(rng.integers(0, 4))], "BiI"[int(rng.integers(0, 3))]
+    m = int(rng.integers(0, 30))
+    header += [f"element face {m}", f"property list {_PY2PLY[lt]} {_PY2PLY[et]} vertex_indices", "end_header"]
+    for _ in range(m):
+        ln = int(rng.integers(0, 7))
+        payload += struct.pack("<" + lt, ln)
+        hi = {"B": 256, "i": 2**31, "I": 2**32}[et]
+        payload += b"".join(struct.pack("<" + et, int(rng.integers(0, hi))) for _ in range(ln))
+    p = str(tmp_path / "gen.ply")
+    write_ply(p, header, payload)
+    want = _compare(H, PO, p)
+    assert "vertex_indices" in want and "face" not in want  # keyed by the PROPERTY name (ply.ml:234)
+
+
+def test_int16_quirk_both_ways(H, PO, tmp_path):
+    """ply.ml reads ONE byte for short / ushort (Bigstring.get_int8 / get_uint8, ply.ml:104-105) while advancing by two
+    (Type.size, ply.ml:90).  The product reads the 16-bit value (the documented divergence).  Values whose high byte is
+    the sign extension of the low one come out the same from both; the others show each side's rule."""
+    small = [(5, 200), (-3, 17), (127, 255), (-128, 0)]       # fits a byte: int8(low byte) == value, uint8(low byte) == value
+    wide = [(300, 513), (-300, 40000), (32767, 65535), (-32768, 256)]
+    for tag, vals in (("small", small), ("wide", wide)):
+        p = str(tmp_path / f"s16_{tag}.ply")
+        write_ply(p, ["format binary_little_endian 1.0", f"element e {len(vals)}", "property short a", "property ushort b",
+                      "property float c", "end_header"], b"".join(struct.pack("<hHf", a, b, 0.5) for a, b in vals))
+        want = PO.of_file(p)["e"]
+        ply = H.Ply(p)
+        assert list(ply.ints("e", "a")) == [a for a, _ in vals] and list(ply.ints("e", "b")) == [b for _, b in vals]  # product: 16 bits
+        quirk_a = [struct.unpack("<b", struct.pack("<h", a)[:1])[0] for a, _ in vals]
+        quirk_b = [struct.pack("<H", b)[0] for _, b in vals]
+        assert want["a"][1] == quirk_a and want["b"][1] == quirk_b                                                    # reference: 1 byte
+        assert (want["a"][1] == [a for a, _ in vals]) == (tag == "small")
+        assert (want["b"][1] == [b for _, b in vals]) == (tag == "small")
+        # the column AFTER the 16-bit ones sits at the right offset on both sides (the size is 2 in both)
+        assert want["c"][1] == [0.5] * len(vals) and list(ply.floats("e", "c")) == [0.5] * len(vals)
+
+
+def test_oracle_quirks_the_product_refuses(H, PO, tmp_path):
+    """Where the reference mis-parses silently or never returns, the product raises: pinned here so that the difference
+    is a decision, not an accident."""
+    # list element first: the reference does not advance past it and reads the vertex floats from the list's bytes
+    p = str(tmp_path / "list_first.ply")
+    write_ply(p, ["format binary_little_endian 1.0", "element face 1", "property list uchar int vertex_indices",
+                  "element vertex 1", "property float x", "end_header"], b"\x03" + struct.pack("<3i", 7, 8, 9) + struct.pack("<f", 2.5))
+    want = PO.of_file(p)
+    assert want["vertex_indices"]["rows"] == [[7, 8, 9]]
+    assert want["vertex"]["x"][1] == [struct.unpack("<f", b"\x03" + struct.pack("<i", 7)[:3])[0]]  # bytes of the LIST, not 2.5
+    with pytest.raises(H.PlyError, match="must be the last element"):
+        H.Ply(p)
+    # no end_header: the reference spins for ever
+    p2 = str(tmp_path / "no_end.ply")
+    write_ply(p2, ["format binary_little_endian 1.0", "element vertex 1", "property float x"], b"")
+    with pytest.raises(PO.PlyHang):
+        PO.of_file(p2)
+    with pytest.raises(H.PlyError, match="end_header"):
+        H.Ply(p2)
+    # element counts: Int.of_string accepts underscores and signs; a negative count dies in Array.create
+    for count, ok in (("1_0", True), ("+3", True), ("-1", False), ("ten", False), ("", False)):
+        p3 = str(tmp_path / "count.ply")
+        write_ply(p3, ["format binary_little_endian 1.0", f"element vertex {count}", "property uchar x", "end_header"], b"\x01" * 16)
+        if ok:
+            assert _compare(H, PO, p3)["vertex"]["x"][1] == [1] * int(count.replace("_", ""))
+        else:
+            with pytest.raises(PO.PlyError):
+                PO.of_file(p3)
+            with pytest.raises(H.PlyError):
+                H.Ply(p3)
+
+
+def test_rejections_agree_with_the_oracle(H, PO, tmp_path):
+    cases = [
+        (["format ascii 1.0", "element vertex 0", "property float x", "end_header"], b"", b"ply\n"),
+        (["format binary_big_endian 1.0", "end_header"], b"", b"ply\n"),
+        (["format binary_little_endian 1.0", "end_header"], b"", b"plx\n"),
+        (["element vertex 1", "property float x", "end_header"], b"\0\0\0\0", b"ply\n"),
+        (["format binary_little_endian 1.0", "element vertex 1", "property quux x", "end_header"], b"", b"ply\n"),
+        (["format binary_little_endian 2.0", "end_header"], b"", b"ply\n"),
+        (["format binary_little_endian 1.0", "element vertex 1", "property float x", "property float x", "end_header"], b"\0" * 8, b"ply\n"),
+        (["format binary_little_endian 1.0", "element face 1", "property float q", "property list uchar int vertex_indices",
+          "end_header"], b"", b"ply\n"),
+        (["format binary_little_endian 1.0", "element vertex 4", "property float x", "end_header"], b"\0" * 8, b"ply\n"),
+        (["format binary_little_endian 1.0", "element face 2", "property list uchar float vertex_indices", "end_header"], b"\0" * 8, b"ply\n"),
+    ]
+    for header, payload, magic in cases:
+        p = str(tmp_path / "bad.ply")
+        write_ply(p, header, payload, magic)
+        with pytest.raises(PO.PlyError):
+            PO.of_file(p)
+        with pytest.raises(H.PlyError):
+            H.Ply(p)
+
+
 def test_float_vertices_uint8_int_faces(H, tmp_path):
     rng = np.random.default_rng(0)
     verts = rng.normal(size=(50, 3)).astype(np.float32)
