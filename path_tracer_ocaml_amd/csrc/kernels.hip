@@ -231,10 +231,17 @@ __device__ __forceinline__ bool pt_slab_hit_exact(const double* nb, V3 o, V3 inv
   return pt_slab_hit(n, o, inv, t_min, t_max);
 }
 
-/* LDS image of a node for LDS-resident scenes: 32 bytes, binary32 -- a FILTER in front of the binary64 slab test.
+/* LDS image of a node for LDS-resident scenes: 48 bytes -- a binary32 FILTER in front of the binary64 slab test, and the
+ * tree THREADED per direction octant so that the walk needs no stack.
  *   words 0..5  mn.x mn.y mn.z mx.x mx.y mx.z rounded to binary32
  *   word 6      branch: lhs | rhs << 16 (node BYTE offsets into this image);  leaf: first slot | real slot count << 16
  *   word 7      bits of `mag` = max |bound| of the node (binary32, rounded up), low 2 bits replaced by the axis (3 = leaf)
+ *   words 8..11 skip[8], u16 each: for a ray whose direction signs are octant o (shape_tree.ml:201), the node the
+ *               reference's recursion visits next once this node's subtree is done (box missed, leaf taken, or both
+ *               children searched) = the far sibling of the nearest ancestor entered through its near child; 0xffff = none.
+ *               Same visiting order as the recursion (near subtree completely, then the far child, tested on arrival against
+ *               the closest hit so far: shape_tree.ml:209-216), hence the same tests and counters, but no push, no pop, no
+ *               stack pointer and no per-lane stack in LDS: ~12 fewer vector instructions and 1 LDS access less per visit.
  * Bbox.is_hit (bbox.ml:40-56) is a boolean of binary64 quantities; the image decides it in binary32 with a rigorous
  * error bound and hands the (rare) undecided lanes to the binary64 code, so the boolean -- and with it every hit, every
  * work counter and every pixel -- is the reference's.  For a ray with |1/d| < 2^100 (else: always binary64):
@@ -246,7 +253,11 @@ __device__ __forceinline__ bool pt_slab_hit_exact(const double* nb, V3 o, V3 inv
  *   + 2^-24 t of hi - lo.  With m2 = 2^-19 * (mag + max|o|) * max|inv| + 2^-21 * t32  (twice that bound):
  *        u >= m2  =>  lo <= hi (hit)        u < -m2  =>  lo > hi (miss)        otherwise: binary64.
  * The undecided share is ~4 m2 / (hi - lo spread) ~ 1e-5 per test, scale-free because mag is the node's own. */
-#define PT_SWZ_NODE_BYTES 32
+#define PT_SWZ_NODE_BYTES 48
+#define PT_SWZ_END 0xffffu
+/* bytes of LDS a wave keeps for traversal stacks: LDS-resident scenes walk the threaded image (no per-lane stack) and
+ * only the camera-ray packet walk keeps its shared (node, mask) stack there: 12 bytes per level, rounded to 16 */
+#define PT_WAVE_STACK_BYTES(LDS_SCENE, StackT, depth) ((LDS_SCENE) ? (size_t)(depth) * 16u : (size_t)(depth) * PT_WAVE * sizeof(StackT))
 #ifndef PT_F32_FILTER_STATS
 #define PT_F32_FILTER_STATS 0 /* diagnostic: count undecided tests in the floor counter */
 #endif
@@ -297,6 +308,7 @@ struct PtTraverser {
   bool exact_slab; /* SWZ: also set when the binary32 filter does not apply to this ray (|1/d| >= 2^100) */
   /* binary32 filter constants of the ray (SWZ only): inv32, -(o * inv)32, k2 = 2^-19 max|inv|, c2 = max|o| k2 + 2^-21 t32 */
   float fix, fiy, fiz, fnx, fny, fnz, k2, c2base, c2, t32;
+  uint32_t skip_off; /* SWZ: byte offset of this ray's octant entry in a node's skip table */
 #if PT_F32_FILTER_STATS
   mutable unsigned long long n_undecided = 0, n_wave_fallbacks = 0;
 #endif
@@ -322,6 +334,7 @@ struct PtTraverser {
     dirs = (d.x >= 0.0 ? 1u : 0u) | (d.y >= 0.0 ? 2u : 0u) | (d.z >= 0.0 ? 4u : 0u);
     exact_slab = !(pt_isfinite(inv.x) && pt_isfinite(inv.y) && pt_isfinite(inv.z));
     if (SWZ) {
+      skip_off = 32u + 2u * dirs;
       const double ax = pt_fabs(inv.x), ay = pt_fabs(inv.y), az = pt_fabs(inv.z);
       const double imax = __builtin_fmax(ax, __builtin_fmax(ay, az));
       const double omax = __builtin_fmax(pt_fabs(o.x), __builtin_fmax(pt_fabs(o.y), pt_fabs(o.z)));
@@ -404,7 +417,7 @@ struct PtTraverser {
         if (pt_lane() == __ffsll((long long)__ballot(1)) - 1) n_wave_fallbacks++;
 #endif
         if (undecided) { /* the reference's arithmetic, on the binary64 node (global memory: L2-resident, rarely read) */
-          const PtNode* np = sv.nodes + (nd >> 5);
+          const PtNode* np = sv.nodes + nd / PT_SWZ_NODE_BYTES;
           const V3 inv64 = v3(1.0 / d.x, 1.0 / d.y, 1.0 / d.z);
           hit = (!(pt_isfinite(inv64.x) && pt_isfinite(inv64.y) && pt_isfinite(inv64.z)))
                     ? pt_slab_hit_exact(np->mn, o, inv64, t_min, r.t)
@@ -426,6 +439,8 @@ struct PtTraverser {
     if (COUNT && (PT_DIAG == 0 || (PT_DIAG <= 2 && !ORIGIN_ZERO))) c_nodes++;
     bool descend = false;
     uint32_t na, nb, n_real;
+    /* threaded image: where to go once this subtree is done (issued beside the node's own reads) */
+    const uint32_t skip = SWZ ? (uint32_t)*(const uint16_t*)(sv.swz_nodes + node + skip_off) : 0u;
     const bool hit = test_box(sv, node, na, nb, n_real);
     if (hit) {
       const uint32_t axis = nb >> 30;
@@ -438,16 +453,21 @@ struct PtTraverser {
         /* Branch: near child first (shape_tree.ml:209), far child deferred */
         const uint32_t lhs = na, rhs = nb & 0x3fffffffu;
         const bool lhs_first = (dirs >> axis) & 1u;
-        PT_STACK_PUSH(stack, sp, lhs_first ? rhs : lhs);
-        ++sp;
+        if (!SWZ) {
+          PT_STACK_PUSH(stack, sp, lhs_first ? rhs : lhs);
+          ++sp;
+        }
         node = lhs_first ? lhs : rhs;
         descend = true;
       }
     }
     if (!descend) {
-      /* the popped node's bbox is tested on the NEXT visit, i.e. after this leaf's packet has been
+      /* the next node's bbox is tested on the NEXT visit, i.e. after this leaf's packet has been
        * intersected and r.t shrunk -- the t_max the reference passes to the far child */
-      if (sp == 0) walking = false;
+      if (SWZ) {
+        if (skip == PT_SWZ_END) walking = false;
+        else node = skip;
+      } else if (sp == 0) walking = false;
       else {
         --sp;
         node = PT_STACK_POP(stack, sp);
@@ -752,7 +772,7 @@ __device__ __forceinline__ PtSceneView pt_scene_view(const PtSceneDev& sc, unsig
   sv.tri = sc.tri;
   sv.kind = sc.slot_kind;
   if (LDS_SCENE) {
-    size_t off = ((size_t)waves_per_block * stack_depth * PT_WAVE * sizeof(StackT) + 63) & ~(size_t)63;
+    size_t off = ((size_t)waves_per_block * PT_WAVE_STACK_BYTES(LDS_SCENE, StackT, stack_depth) + 63) & ~(size_t)63;
     unsigned char* l_nodes = lds_raw + off;
     off += (size_t)sc.n_nodes * PT_SWZ_NODE_BYTES;
     const int total_slots = sc.n_slots + sc.n_floor;
@@ -778,6 +798,11 @@ __device__ __forceinline__ PtSceneView pt_scene_view(const PtSceneDev& sc, unsig
                   : ((src->a * PT_SWZ_NODE_BYTES) | (((src->b & 0x3fffffffu) * PT_SWZ_NODE_BYTES) << 16));
       /* rounded up, then the two lowest mantissa bits carry the axis (a relative change below 2^-21, inside the slack) */
       w[7] = ((__float_as_uint(mag * 1.000001f) + 4u) & ~3u) | axis;
+      uint16_t* sk = (uint16_t*)(w + 8);
+      for (int o = 0; o < 8; ++o) {
+        const uint32_t nx = sc.node_skip[(size_t)k * 8 + o];
+        sk[o] = nx == 0xffffu ? (uint16_t)PT_SWZ_END : (uint16_t)(nx * PT_SWZ_NODE_BYTES);
+      }
     }
     {
       const uint4* src = (const uint4*)sc.sph;
@@ -908,7 +933,7 @@ __global__ __launch_bounds__(PT_TRACE_BLOCK_OF(MODE, LDS_SCENE), (LDS_SCENE && M
   const int wave_in_block = (int)(threadIdx.x >> 6);
   /* LDS-resident scenes have < 65536 nodes: 16-bit stack entries halve the stack footprint */
   typedef typename std::conditional<LDS_SCENE, uint16_t, uint32_t>::type StackT;
-  StackT* stack = (StackT*)lds_raw + (size_t)wave_in_block * stack_depth * PT_WAVE + lane;
+  StackT* stack = (StackT*)(lds_raw + (size_t)wave_in_block * PT_WAVE_STACK_BYTES(LDS_SCENE, StackT, stack_depth)) + (LDS_SCENE ? 0 : lane);
   __shared__ uint32_t lds_chunk_ctr;
   if (threadIdx.x == 0) lds_chunk_ctr = 0u;
   const PtSceneView sv = pt_scene_view<MODE, LDS_SCENE, StackT>(sc, lds_raw, stack_depth);
@@ -921,7 +946,7 @@ __global__ __launch_bounds__(PT_TRACE_BLOCK_OF(MODE, LDS_SCENE), (LDS_SCENE && M
 
   if (PACKET) { /* the 64 rays of the wave walk the tree together (pt_trace_packet) */
     /* the wave's private stack area (stack_depth x 64 entries) holds the shared (node, mask) stack: 12 B per level */
-    uint32_t* wstack = (uint32_t*)((StackT*)lds_raw + (size_t)wave_in_block * stack_depth * PT_WAVE);
+    uint32_t* wstack = (uint32_t*)(lds_raw + (size_t)wave_in_block * PT_WAVE_STACK_BYTES(LDS_SCENE, StackT, stack_depth));
     while (feed.take(chunk)) {
       const uint32_t i = chunk * PT_WAVE + lane;
       bool valid = i < n;
@@ -1022,7 +1047,7 @@ __global__ __launch_bounds__(PT_TRACE_BLOCK_OF(MODE, LDS_SCENE), PT_TRACE_GLOBAL
   const int wave_in_block = (int)(threadIdx.x >> 6);
   const uint32_t waves_per_block = blockDim.x >> 6;
   typedef typename std::conditional<LDS_SCENE, uint16_t, uint32_t>::type StackT;
-  StackT* stack = (StackT*)lds_raw + (size_t)wave_in_block * stack_depth * PT_WAVE + lane;
+  StackT* stack = (StackT*)(lds_raw + (size_t)wave_in_block * PT_WAVE_STACK_BYTES(LDS_SCENE, StackT, stack_depth)) + (LDS_SCENE ? 0 : lane);
   const PtSceneView sv = pt_scene_view<MODE, LDS_SCENE, StackT>(sc, lds_raw, stack_depth);
   const uint32_t n = *q.count;
   const uint32_t gwave = blockIdx.x * waves_per_block + wave_in_block;

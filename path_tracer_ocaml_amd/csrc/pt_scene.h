@@ -98,6 +98,9 @@ struct PtSceneDev {
   const PtMaterial* materials;
   const PtTexture* textures;
   const PtShadeRec* slot_shade; /* per slot (padding slots zero) */
+  /* n_nodes x 8 (u16 node indices, 0xffff = none): per direction octant, the node visited after a node's subtree
+   * (the threading of the LDS node image, kernels.hip); NULL when the tree has 65535 nodes or more */
+  const uint16_t* node_skip;
   double cam_llx, cam_lly, cam_vx, cam_vy;
   int32_t bg_kind;
   int32_t pad0;
