@@ -101,6 +101,12 @@ struct PtSceneDev {
   /* n_nodes x 8 (u16 node indices, 0xffff = none): per direction octant, the node visited after a node's subtree
    * (the threading of the LDS node image, kernels.hip); NULL when the tree has 65535 nodes or more */
   const uint16_t* node_skip;
+  /* unit vector (camera space) along which the primitives' centres vary least = the normal of the scene's ground plane when it
+   * has one.  A HEURISTIC sort key only (shade bins survivors by the elevation of the new direction above that plane, a
+   * predictor of how long the next walk is); it never enters a pixel value. */
+  double sort_axis[3];
+  int32_t sort_by_elevation; /* 1: the centres do lie in a slab (smallest variance < 2 % of the largest): bin by elevation; 0: by direction octant */
+  int32_t pad1;
   double cam_llx, cam_lly, cam_vx, cam_vy;
   int32_t bg_kind;
   int32_t pad0;

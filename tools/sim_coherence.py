@@ -156,3 +156,72 @@ for win in (4096, 32768, len(o)):
         evaluate(oo[sub], dd[sub], f"window {win if win < len(o) else 'all':>6}, key (octant, {cells}x{cells} cell)")
 perm = rng.permutation(len(o))
 evaluate(o[perm][sub], dv[perm][sub], "random order")
+
+# ---- keys that predict the LENGTH of the walk instead of its place: elevation of the direction above the ground
+# plane (rays that climb leave the slab of spheres after a few node tests, grazing rays cross the whole scene)
+up = np.array([cx_[0], cy_[0], cz_[0]])  # the ground sphere's centre is straight "down" from the scene in camera space
+up = -up / np.linalg.norm(up)
+def elev_key(dv, levels, with_octant):
+    e = np.clip(((dv @ up) + 1.0) * 0.5 * levels, 0, levels - 1e-9).astype(int)
+    return (octant(dv) * levels + e) if with_octant else e
+for win in (512, 4096):
+    for levels, wo in ((4, True), (8, False), (16, False), (8, True)):
+        oo, dd = o.copy(), dv.copy()
+        for s in range(0, len(o), win):
+            k = np.argsort(elev_key(dv[s:s + win], levels, wo), kind="stable")
+            oo[s:s + win], dd[s:s + win] = o[s:s + win][k], dv[s:s + win][k]
+        evaluate(oo[sub], dd[sub], f"window {win:>5}, key ({'octant, ' if wo else ''}elevation/{levels})")
+
+# ---- how far any key could go: sort each 512-window by the TRUE number of node tests of each ray (an oracle key)
+true_visits = np.zeros(len(o), dtype=np.int64)
+for w0 in range(0, sub.stop, 64):
+    oo, dd = o[w0:w0 + 64], dv[w0:w0 + 64]
+    oc = octant(dd)
+    for k in np.unique(oc):
+        m = np.nonzero(oc == k)[0]
+        wk = Walk(oo[m], dd[m]); wk.rec(0, np.arange(len(m)))
+        true_visits[w0 + m] = wk.visits + 4 * wk.slots
+for win in (512, 4096):
+    oo, dd = o.copy(), dv.copy()
+    for s in range(0, sub.stop, win):
+        k = np.argsort(true_visits[s:s + win], kind="stable")
+        oo[s:s + win], dd[s:s + win] = o[s:s + win][k], dv[s:s + win][k]
+    evaluate(oo[sub], dd[sub], f"window {win:>5}, ORACLE key (true walk length)")
+# elevation x height of the origin above the plane
+def elev_height_key(o_, dv, le, lh):
+    e = np.clip(((dv @ up) + 1.0) * 0.5 * le, 0, le - 1e-9).astype(int)
+    hgt = (o_ - o_.mean(0)) @ up
+    hq = np.clip(np.digitize(hgt, np.quantile(hgt, np.linspace(0, 1, lh + 1)[1:-1])), 0, lh - 1)
+    return e * lh + hq
+for le, lh in ((4, 2), (8, 2), (4, 4)):
+    oo, dd = o.copy(), dv.copy()
+    for s in range(0, len(o), 512):
+        k = np.argsort(elev_height_key(o[s:s + 512], dv[s:s + 512], le, lh), kind="stable")
+        oo[s:s + 512], dd[s:s + 512] = o[s:s + 512][k], dv[s:s + 512][k]
+    evaluate(oo[sub], dd[sub], f"window   512, key (elevation/{le} x origin height/{lh})")
+
+# ---- slab-crossing length: distance the ray travels before it leaves the slab that holds the small primitives
+ctr = np.stack([cx_, cy_, cz_], 1)[cr_ < 10]
+hh = ctr @ up
+lo_h, hi_h = (hh - cr_[cr_ < 10]).min(), (hh + cr_[cr_ < 10]).max()
+def slab_key(o_, dv, levels):
+    e = dv @ up
+    h0 = o_ @ up
+    L = np.where(e > 0, (hi_h - h0) / np.maximum(e, 1e-9), (h0 - lo_h) / np.maximum(-e, 1e-9))
+    L = np.clip(L, 1e-3, 1e3)
+    q = np.log(L)
+    edges = np.quantile(q, np.linspace(0, 1, levels + 1)[1:-1])
+    return np.digitize(q, edges)
+def slab_key_fixed(o_, dv, levels):  # fixed log-spaced edges (what a kernel can do without a quantile pass)
+    e = dv @ up
+    h0 = o_ @ up
+    L = np.where(e > 0, (hi_h - h0) / np.maximum(e, 1e-9), (h0 - lo_h) / np.maximum(-e, 1e-9))
+    q = np.log2(np.clip(L / (hi_h - lo_h), 2.0 ** -1, 2.0 ** (levels - 1.001)))  # in slab thicknesses
+    return np.clip((q + 1).astype(int), 0, levels - 1)
+for name, fn in (("slab length quantiles/8", lambda a, b: slab_key(a, b, 8)), ("slab length log2 steps/8", lambda a, b: slab_key_fixed(a, b, 8))):
+    oo, dd = o.copy(), dv.copy()
+    for s in range(0, len(o), 512):
+        k = np.argsort(fn(o[s:s + 512], dv[s:s + 512]), kind="stable")
+        oo[s:s + 512], dd[s:s + 512] = o[s:s + 512][k], dv[s:s + 512][k]
+    evaluate(oo[sub], dd[sub], f"window   512, key ({name})")
+print("slab", lo_h, hi_h)
