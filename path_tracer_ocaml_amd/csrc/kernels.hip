@@ -616,14 +616,33 @@ struct PtTraverser {
  * lanes that hold a leaf test its packet TOGETHER.  Interleaving the two, as the recursive reference does, would
  * run the packet loop for one or two lanes at a time.  The order of node tests and packet tests of each individual
  * ray is unchanged. */
+/* Tail cut (threaded LDS scenes only: the whole state of a walk in progress is the node it stands on, the closest hit so
+ * far and its slot).  The wave stops a chunk once fewer than `min_active` of its rays are still walking; those rays are
+ * not finished: the caller parks their state and resumes them later TOGETHER with the stragglers of its other chunks
+ * (k_trace).  A resumed ray continues at `node` with `t` / `slot` restored, i.e. it performs exactly the box and packet
+ * tests it had left, in the same order. */
+struct PtTailCtl {
+  int min_active;   /* in: stop when fewer rays than this are walking (0 = run to completion) */
+  bool resume;      /* in: this lane continues a parked walk */
+  uint32_t node;    /* in (resume) / out (unfinished): byte offset of the node to visit next */
+  double t;         /* in (resume): closest hit so far */
+  int slot;
+  bool unfinished;  /* out: the ray is still walking */
+};
 template <int MODE, bool COUNT, bool ORIGIN_ZERO, typename StackT, bool SWZ = false>
 __device__ __forceinline__ PtTraceResult pt_trace_ray(const PtSceneDev& sc, const PtSceneView& sv, StackT* stack,
                                                       V3 o, V3 d, unsigned long long& c_nodes,
                                                       unsigned long long& c_prims, unsigned long long& c_floor,
-                                                      bool valid = true) {
+                                                      bool valid = true, PtTailCtl* tc = nullptr) {
   PtTraverser<MODE, COUNT, ORIGIN_ZERO, StackT, SWZ> tr;
   unsigned long long no_count = 0; /* lanes without a ray run begin() on a dummy ray: keep them out of the counters */
   tr.begin(sc, sv, o, d, valid ? c_floor : no_count);
+  if (tc && tc->resume) {
+    tr.node = tc->node;
+    tr.r.t = tc->t;
+    tr.r.slot = tc->slot;
+    if (SWZ) tr.update_t32();
+  }
   while (valid && (tr.walking || tr.leaf_n > 0)) {
     for (;;) {
       /* keep walking while enough lanes still want a node step; once fewer than PT_WALK_MIN do and some lane
@@ -637,6 +656,13 @@ __device__ __forceinline__ PtTraceResult pt_trace_ray(const PtSceneDev& sc, cons
       tr.node_step(sv, stack, c_nodes, c_prims);
     }
     if (tr.leaf_n > 0) tr.packet(sv, c_nodes, c_floor);
+    /* nobody holds a leaf here: a safe place to stop.  The ballot sees the rays that are still walking (finished
+     * lanes have left the loop), and every one of them sees the same count. */
+    if (tc && (int)__popcll(__ballot(tr.walking)) < tc->min_active) break;
+  }
+  if (tc) {
+    tc->unfinished = valid && tr.walking;
+    tc->node = tr.node;
   }
 #if PT_F32_FILTER_STATS
   if (COUNT && SWZ) { c_floor += tr.n_undecided; c_floor += tr.n_wave_fallbacks << 32; }
@@ -911,6 +937,9 @@ struct PtChunkFeed {
 #ifndef PT_TRACE_GLOBAL_WAVES
 #define PT_TRACE_GLOBAL_WAVES 4
 #endif
+#ifndef PT_TAIL_CUT
+#define PT_TAIL_CUT 16 /* 0 = off */
+#endif
 #ifndef PT_TRACE_BLOCK_LDS
 #define PT_TRACE_BLOCK_LDS 1024 /* workgroup size when the scene is copied to LDS (one copy per workgroup) */
 #endif
@@ -931,7 +960,7 @@ template <int MODE, bool COUNT, bool PRIMARY, bool LDS_SCENE, bool PACKET>
  * writes per launch on cornell). */
 __global__ __launch_bounds__(PT_TRACE_BLOCK_OF(MODE, LDS_SCENE), (LDS_SCENE && MODE == PT_MODE_SIMD) ? PT_TRACE_LDS_WAVES : PT_TRACE_GLOBAL_WAVES) void k_trace(PtSceneDev sc, PtQueue q, PtHits hits, int stack_depth,
                                                PtCounters* counters, PtGenParams g, const double* __restrict__ alpha,
-                                               uint32_t n_primary, uint32_t* work) {
+                                               uint32_t n_primary, uint32_t* work, uint4* susp) {
   extern __shared__ __attribute__((aligned(64))) unsigned char lds_raw[];
   const int lane = pt_lane();
   const int wave_in_block = (int)(threadIdx.x >> 6);
@@ -976,26 +1005,55 @@ __global__ __launch_bounds__(PT_TRACE_BLOCK_OF(MODE, LDS_SCENE), (LDS_SCENE && M
         }
       }
     }
-  } else
-  while (feed.take(chunk)) { /* no `continue` below: every lane comes back to take() together (it is wave-uniform) */
-    const uint32_t i = chunk * PT_WAVE + lane;
-    bool valid = i < n;
-    V3 o = v3(0.0, 0.0, 0.0), d = v3(0.0, 0.0, -1.0); /* P3.origin */
-    if (valid) {
-      if (PRIMARY) {
-        const PtPrimarySample ps = pt_primary_decode(g, i);
-        valid = ps.valid;
-        if (valid) d = pt_primary_dir(sc, g, ps, alpha);
+  } else {
+    /* One ray per lane.  TAIL: see PtTailCtl -- a chunk ends when fewer than PT_TAIL_CUT of its rays are still walking;
+     * their states (16 bytes each) go to this wave's list in `susp` and once 64 - PT_TAIL_CUT have gathered the wave walks
+     * them as a chunk of their own.  tools/sim_coherence.py: 0.527 -> 0.435 wave steps per ray at 16. */
+    constexpr bool TAIL = PT_TAIL_CUT > 0 && LDS_SCENE && MODE == PT_MODE_SIMD && !PRIMARY && PT_DIAG == 0;
+    uint4* my_susp = TAIL ? susp + ((size_t)blockIdx.x * (blockDim.x >> 6) + wave_in_block) * PT_WAVE : nullptr;
+    uint32_t n_susp = 0; /* wave-uniform */
+    bool more = true;
+    for (;;) { /* no `continue` past a point where lanes have diverged: take() is wave-uniform */
+      bool resume = false, valid = false;
+      uint32_t i = 0;
+      uint4 parked = make_uint4(0, 0, 0, 0);
+      if (TAIL && (n_susp > (uint32_t)(PT_WAVE - PT_TAIL_CUT) || (!more && n_susp > 0))) {
+        resume = true;
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); /* this wave's own parked states, written below */
+        valid = (uint32_t)lane < n_susp;
+        if (valid) parked = my_susp[lane];
+        i = parked.x;
+        n_susp = 0;
       } else {
-        o = v3(q.ox[i], q.oy[i], q.oz[i]);
-        d = v3(q.dx[i], q.dy[i], q.dz[i]);
+        if (!more) break;
+        more = feed.take(chunk);
+        if (more) {
+          i = chunk * PT_WAVE + lane;
+          valid = i < n;
+        }
       }
-    }
-    {
-      if (COUNT && valid) c_seg++;
+      V3 o = v3(0.0, 0.0, 0.0), d = v3(0.0, 0.0, -1.0); /* P3.origin */
+      if (valid) {
+        if (PRIMARY) {
+          const PtPrimarySample ps = pt_primary_decode(g, i);
+          valid = ps.valid;
+          if (valid) d = pt_primary_dir(sc, g, ps, alpha);
+        } else {
+          o = v3(q.ox[i], q.oy[i], q.oz[i]);
+          d = v3(q.dx[i], q.dy[i], q.dz[i]);
+        }
+      }
+      if (COUNT && valid && !resume) c_seg++;
       const unsigned long long diag_n0 = c_nodes;
-      /* every lane goes in (the predicated walk has wave-uniform loops); lanes without a ray commit nothing */
-      const PtTraceResult r = pt_trace_ray<MODE, COUNT, PRIMARY, StackT, LDS_SCENE>(sc, sv, stack, o, d, c_nodes, c_prims, c_floor, valid);
+      PtTailCtl tc;
+      tc.min_active = (TAIL && more) ? PT_TAIL_CUT : 0; /* the last chunks of a wave run to completion */
+      tc.resume = resume && valid;
+      tc.node = parked.y & 0xffffu;
+      tc.slot = (int)(parked.y >> 16) == 0xffff ? -1 : (int)(parked.y >> 16);
+      tc.t = __hiloint2double((int)parked.w, (int)parked.z);
+      tc.unfinished = false;
+      /* every lane goes in (wave-level ballots inside); lanes without a ray commit nothing */
+      const PtTraceResult r = pt_trace_ray<MODE, COUNT, PRIMARY, StackT, LDS_SCENE>(sc, sv, stack, o, d, c_nodes, c_prims, c_floor, valid, TAIL ? &tc : nullptr);
       if (COUNT && PT_DIAG == 2 && !PRIMARY && valid) {
         unsigned long long m = c_nodes - diag_n0;
         for (int off = 32; off > 0; off >>= 1) {
@@ -1005,12 +1063,25 @@ __global__ __launch_bounds__(PT_TRACE_BLOCK_OF(MODE, LDS_SCENE), (LDS_SCENE && M
         PT_DIAG_WAVE_SLOTS(c_floor);
         if (lane == 0) c_floor += m * 64 - 64;
       }
-      if (valid) {
+      const bool park = TAIL && tc.unfinished;
+      if (valid && !park) {
         hits.t[i] = r.t;
         hits.slot[i] = r.slot;
         if (MODE == PT_MODE_ARRAY && sc.has_triangles) {
           hits.u[i] = r.u;
           hits.v[i] = r.v;
+        }
+      }
+      if (TAIL) {
+        const unsigned long long pm = __ballot(park);
+        if (pm != 0) {
+          if (park) {
+            const uint32_t k = n_susp + (uint32_t)__popcll(pm & ((1ull << lane) - 1ull));
+            my_susp[k] = make_uint4(i, tc.node | ((uint32_t)(r.slot < 0 ? 0xffff : r.slot) << 16),
+                                    (uint32_t)__double2loint(r.t), (uint32_t)__double2hiint(r.t));
+          }
+          n_susp += (uint32_t)__popcll(pm);
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         }
       }
     }

@@ -225,3 +225,47 @@ for name, fn in (("slab length quantiles/8", lambda a, b: slab_key(a, b, 8)), ("
         oo[s:s + 512], dd[s:s + 512] = o[s:s + 512][k], dv[s:s + 512][k]
     evaluate(oo[sub], dd[sub], f"window   512, key ({name})")
 print("slab", lo_h, hi_h)
+
+# ---- tail cut with wave-local resume: a chunk stops when fewer than T rays are still walking; the stragglers' (tiny,
+# stackless) states wait in a per-wave list and are resumed together once 64 - T of them have gathered
+def tail_cut_model(cost, T, waves=64, resume_overhead=3.0):
+    """cost: per-ray walk length in queue order.  A wave owns every `waves`-th chunk.  Returns wave steps per ray."""
+    n = len(cost) // 64 * 64
+    chunks = cost[:n].reshape(-1, 64).astype(float)
+    steps = 0.0
+    for w in range(waves):
+        pend = []
+        mine = chunks[w::waves]
+        for k, c in enumerate(mine):
+            last = k == len(mine) - 1
+            def run(c, T_):
+                nonlocal steps
+                if T_ <= 1 or len(c) < T_:
+                    steps += c.max() if len(c) else 0.0
+                    return np.zeros(0)
+                s = np.sort(c)[-T_]            # when the T-th longest finishes, T - 1 are left
+                steps += s
+                return c[c > s] - s
+            left = run(c, T)
+            pend.extend(left.tolist())
+            while len(pend) >= 64 - T + 1 or (last and pend):
+                take, pend = np.array(pend[:64]) + resume_overhead, pend[64:]
+                left = run(take, 0 if (last and not pend) else T)
+                pend.extend(left.tolist())
+    return steps / n
+cost_elev = None
+oo, dd = o.copy(), dv.copy()
+for s in range(0, len(o), 512):
+    k = np.argsort(elev_key(dv[s:s + 512], 8, False), kind="stable")
+    oo[s:s + 512], dd[s:s + 512] = o[s:s + 512][k], dv[s:s + 512][k]
+cost = np.zeros(sub.stop)
+for w0 in range(0, sub.stop, 64):
+    a, b = oo[w0:w0 + 64], dd[w0:w0 + 64]
+    oc = octant(b)
+    for k in np.unique(oc):
+        m = np.nonzero(oc == k)[0]
+        wk = Walk(a[m], b[m]); wk.rec(0, np.arange(len(m)))
+        cost[w0 + m] = wk.visits + 0.7 * wk.slots   # a slot step costs ~0.7 of a node step
+print("tail-cut model on the elevation-sorted queue (combined node + slot steps per ray):")
+for T in (0, 4, 8, 16, 24, 32):
+    print(f"  T = {T:2d}: {tail_cut_model(cost, T):.3f} wave steps per ray")
