@@ -626,6 +626,7 @@ struct PtTailCtl {
   bool resume;      /* in: this lane continues a parked walk */
   uint32_t node;    /* in (resume) / out (unfinished): byte offset of the node to visit next */
   double t;         /* in (resume): closest hit so far */
+  double u, v;      /* in (resume): its barycentrics (triangle scenes) */
   int slot;
   bool unfinished;  /* out: the ray is still walking */
 };
@@ -636,10 +637,13 @@ __device__ __forceinline__ PtTraceResult pt_trace_ray(const PtSceneDev& sc, cons
                                                       bool valid = true, PtTailCtl* tc = nullptr) {
   PtTraverser<MODE, COUNT, ORIGIN_ZERO, StackT, SWZ> tr;
   unsigned long long no_count = 0; /* lanes without a ray run begin() on a dummy ray: keep them out of the counters */
-  tr.begin(sc, sv, o, d, valid ? c_floor : no_count);
+  /* a resumed walk has had its floor pre-test (its outcome is part of the parked state): not counted again */
+  tr.begin(sc, sv, o, d, (valid && !(tc && tc->resume)) ? c_floor : no_count);
   if (tc && tc->resume) {
     tr.node = tc->node;
     tr.r.t = tc->t;
+    tr.r.u = tc->u;
+    tr.r.v = tc->v;
     tr.r.slot = tc->slot;
     if (SWZ) tr.update_t32();
   }
@@ -1009,19 +1013,21 @@ __global__ __launch_bounds__(PT_TRACE_BLOCK_OF(MODE, LDS_SCENE), (LDS_SCENE && M
     /* One ray per lane.  TAIL: see PtTailCtl -- a chunk ends when fewer than PT_TAIL_CUT of its rays are still walking;
      * their states (16 bytes each) go to this wave's list in `susp` and once 64 - PT_TAIL_CUT have gathered the wave walks
      * them as a chunk of their own.  tools/sim_coherence.py: 0.527 -> 0.435 wave steps per ray at 16. */
-    constexpr bool TAIL = PT_TAIL_CUT > 0 && LDS_SCENE && MODE == PT_MODE_SIMD && !PRIMARY && PT_DIAG == 0;
-    uint4* my_susp = TAIL ? susp + ((size_t)blockIdx.x * (blockDim.x >> 6) + wave_in_block) * PT_WAVE : nullptr;
+    constexpr bool TAIL = PT_TAIL_CUT > 0 && LDS_SCENE && !PRIMARY && PT_DIAG == 0;
+    constexpr bool TAIL_UV = TAIL && MODE == PT_MODE_ARRAY; /* triangle hits carry barycentrics: a second 16 bytes per state */
+    uint4* my_susp = TAIL ? susp + ((size_t)blockIdx.x * (blockDim.x >> 6) + wave_in_block) * (PT_WAVE * 2) : nullptr;
     uint32_t n_susp = 0; /* wave-uniform */
     bool more = true;
     for (;;) { /* no `continue` past a point where lanes have diverged: take() is wave-uniform */
       bool resume = false, valid = false;
       uint32_t i = 0;
-      uint4 parked = make_uint4(0, 0, 0, 0);
+      uint4 parked = make_uint4(0, 0, 0, 0), parked_uv = make_uint4(0, 0, 0, 0);
       if (TAIL && (n_susp > (uint32_t)(PT_WAVE - PT_TAIL_CUT) || (!more && n_susp > 0))) {
         resume = true;
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); /* this wave's own parked states, written below */
         valid = (uint32_t)lane < n_susp;
         if (valid) parked = my_susp[lane];
+        if (TAIL_UV && valid) parked_uv = my_susp[PT_WAVE + lane];
         i = parked.x;
         n_susp = 0;
       } else {
@@ -1051,6 +1057,8 @@ __global__ __launch_bounds__(PT_TRACE_BLOCK_OF(MODE, LDS_SCENE), (LDS_SCENE && M
       tc.node = parked.y & 0xffffu;
       tc.slot = (int)(parked.y >> 16) == 0xffff ? -1 : (int)(parked.y >> 16);
       tc.t = __hiloint2double((int)parked.w, (int)parked.z);
+      tc.u = __hiloint2double((int)parked_uv.y, (int)parked_uv.x);
+      tc.v = __hiloint2double((int)parked_uv.w, (int)parked_uv.z);
       tc.unfinished = false;
       /* every lane goes in (wave-level ballots inside); lanes without a ray commit nothing */
       const PtTraceResult r = pt_trace_ray<MODE, COUNT, PRIMARY, StackT, LDS_SCENE>(sc, sv, stack, o, d, c_nodes, c_prims, c_floor, valid, TAIL ? &tc : nullptr);
@@ -1079,6 +1087,8 @@ __global__ __launch_bounds__(PT_TRACE_BLOCK_OF(MODE, LDS_SCENE), (LDS_SCENE && M
             const uint32_t k = n_susp + (uint32_t)__popcll(pm & ((1ull << lane) - 1ull));
             my_susp[k] = make_uint4(i, tc.node | ((uint32_t)(r.slot < 0 ? 0xffff : r.slot) << 16),
                                     (uint32_t)__double2loint(r.t), (uint32_t)__double2hiint(r.t));
+            if (TAIL_UV)
+              my_susp[PT_WAVE + k] = make_uint4((uint32_t)__double2loint(r.u), (uint32_t)__double2hiint(r.u), (uint32_t)__double2loint(r.v), (uint32_t)__double2hiint(r.v));
           }
           n_susp += (uint32_t)__popcll(pm);
           __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
