@@ -79,7 +79,8 @@ for k in kernels:
     if busy:
         cycles = busy / 32.0
         av, tc, waves, wca = g("SQ_ACTIVE_INST_VALU", "sq_a"), g("SQ_THREAD_CYCLES_VALU", "sq_a"), g("SQ_WAVES", "sq_a"), g("SQ_WAVE_CYCLES", "sq_a")
-        e["valu_busy"] = 4.0 * av / (1024.0 * cycles)
+        e["valu_busy_raw"] = 4.0 * av / (1024.0 * cycles)  # can pass 1: the counter charges a whole quad-cycle per instruction
+        e["valu_busy"] = min(1.0, e["valu_busy_raw"])
         e["lane_util"] = tc / (64.0 * av)
         e["useful_issue_frac"] = e["valu_busy"] * e["lane_util"]
         e["valu_insts_per_launch"] = g("SQ_INSTS_VALU", "sq_a") / nl
