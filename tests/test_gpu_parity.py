@@ -324,7 +324,7 @@ def test_gpu_bvh_build_equals_oracle_tree(P, oracle, name):
 
 
 # ---------------------------------------------------------------- seeded sweep over render configurations
-@pytest.mark.parametrize("seed", range(6))
+@pytest.mark.parametrize("seed", range(12))
 def test_random_configs_raw_sums_bitwise(P, oracle, seed, monkeypatch):
     """Random (scene, size, spp, depth, batching, band sharding, trace-kernel choice): the raw per-pixel sums are the
     oracle's bit for bit whatever way the work is cut up."""
@@ -338,6 +338,9 @@ def test_random_configs_raw_sums_bitwise(P, oracle, seed, monkeypatch):
     monkeypatch.setenv("PTX_TRACE_STREAM", str(int(rng.integers(0, 2))))  # both trace kernels on every kind of scene
     monkeypatch.setenv("PTX_STREAMS", str(int(rng.integers(1, 5))))  # batches in flight
     monkeypatch.setenv("PTX_SHADE_SPLIT", str(int(rng.integers(0, 2))))  # category-sorting shade kernel / per-category stage queues
+    monkeypatch.setenv("PTX_TRACE_BLOCK", str(int(rng.choice([0, 64, 256, 512, 1024]))))  # trace workgroup size (0 = by schedule)
+    monkeypatch.setenv("PTX_TRACE_WGS", str(int(rng.integers(0, 4))))  # trace workgroups per CU (0 = as many as fit)
+    monkeypatch.setenv("PTX_BIN_KEY", str(int(rng.integers(0, 2))))  # survivors binned by octant / by elevation
     o_scene = oracle.Scene(d.ptr, d)
     g_scene = P.Scene(d.ptr, 0, keepalive=d)
     c = o_scene.render(w, h, spp, depth, threads=8, want_raw=True)
@@ -354,6 +357,29 @@ def test_random_configs_raw_sums_bitwise(P, oracle, seed, monkeypatch):
     nbad = int((bits(full.cpu().numpy()) != bits(c["raw"])).sum())
     assert nbad == 0, f"{kind} {w}x{h} spp {spp} depth {depth} ppb {ppb} bands {band_rows}/{world}: {nbad} raw values differ"
     g_scene.close()
+
+
+@pytest.mark.parametrize("kind,block,wgs", [("shirley", 64, 1), ("shirley", 1024, 1), ("shirley", 512, 0), ("shirley_no_simd", 128, 1), ("cornell", 64, 2)])
+def test_tail_cut_and_threaded_walk_under_small_grids(P, oracle, kind, block, wgs, monkeypatch):
+    """The bounce-ray trace parks the stragglers of every chunk and resumes them per wave (PtTailCtl).  Small workgroups and
+    one workgroup per CU give every wave hundreds of chunks, i.e. many park / resume rounds including re-parked rays and the
+    final drain; the raw sums, the hits and every work counter must still be the oracle's."""
+    torch = pytest.importorskip("torch")
+    monkeypatch.setenv("PTX_TRACE_BLOCK", str(block))
+    monkeypatch.setenv("PTX_TRACE_WGS", str(wgs))
+    monkeypatch.setenv("PTX_STREAMS", "1")
+    w, h, spp, depth = 512, 256, 6, 10
+    d = {"shirley": lambda: oracle.desc_shirley(w, h), "shirley_no_simd": lambda: oracle.desc_shirley(w, h, no_simd=True),
+         "cornell": lambda: oracle.desc_cornell(w, h)}[kind]()
+    c = oracle.Scene(d.ptr, d).render(w, h, spp, depth, threads=8, want_raw=True, count=True)
+    g = P.Scene(d.ptr, 0, keepalive=d)
+    assert g.stats()["traversal_in_lds"]
+    raw = torch.zeros((h, w, 3), dtype=torch.float64, device="cuda:0")
+    st = g.render_raw_device(P.render_params(w, h, spp, depth, count_work=True), raw.data_ptr())
+    assert np.array_equal(bits(raw.cpu().numpy()), bits(c["raw"]))
+    for k in ("segments", "nodes_tested", "prims_tested"):
+        assert st[k] == c["counters"][k], k
+    g.close()
 
 
 @pytest.mark.parametrize("kind", ["shirley", "cornell", "ganesha"])
