@@ -257,14 +257,21 @@ __device__ __forceinline__ bool pt_slab_hit_exact(const double* nb, V3 o, V3 inv
 #define PT_SWZ_END 0xffffu
 /* bytes of LDS a wave keeps for traversal stacks: LDS-resident scenes walk the threaded image (no per-lane stack) and
  * only the camera-ray packet walk keeps its shared (node, mask) stack there: 12 bytes per level, rounded to 16 */
-#define PT_WAVE_STACK_BYTES(LDS_SCENE, StackT, depth) ((LDS_SCENE) ? (size_t)(depth) * 16u : (size_t)(depth) * PT_WAVE * sizeof(StackT))
+#define PT_WAVE_STACK_BYTES(LDS_SCENE, StackT, depth) ((LDS_SCENE) ? (size_t)(depth) * 16u : (std::is_same<StackT, PtThreadTag>::value ? (size_t)0 : (size_t)(depth) * PT_WAVE * sizeof(StackT)))
 #ifndef PT_F32_FILTER_STATS
 #define PT_F32_FILTER_STATS 0 /* diagnostic: count undecided tests in the floor counter */
 #endif
 
 /* where the traversal data of this launch lives: HBM/L2 (large scenes) or an LDS copy (small scenes) */
+/* StackT of a walk that needs no stack: scenes traversed from HBM / L2 follow per-octant skip links like the LDS image
+ * does (PtSceneDev.node_skip32), which frees the LDS the per-lane stacks took (depth x 256 bytes per wave: it capped
+ * the ganesha-like scene at 3 waves per SIMD where its registers allow 4) */
+struct PtThreadTag {};
+
 struct PtSceneView {
   const PtNode* nodes;
+  const uint32_t* skip32; /* threaded global walk: n_nodes x 8, 0xffffffff = none */
+  const unsigned char* nodes32; /* 32-byte binary32 image of the nodes for the walk from HBM / L2 */
   const unsigned char* swz_nodes; /* LDS-resident scenes: the binary32 filter image, PT_SWZ_NODE_BYTES per node */
   const double* sph;
   const double* tri;
@@ -280,8 +287,12 @@ struct PtTraceResult {
  * one column per lane (conflict-free ds_write_b32 / ds_read_b32).  A far child's bbox is tested when it
  * is POPPED, against the closest hit so far -- exactly the t_max the reference's recursion passes
  * (shape_tree.ml:210-216). */
-#define PT_STACK_PUSH(stk, sp, val) ((stk)[(sp) * PT_WAVE] = (StackT)(val))
-#define PT_STACK_POP(stk, sp) ((uint32_t)(stk)[(sp) * PT_WAVE])
+template <class T> __device__ __forceinline__ void pt_stack_push(T* stk, int sp, uint32_t val) { stk[sp * PT_WAVE] = (T)val; }
+template <class T> __device__ __forceinline__ uint32_t pt_stack_pop(const T* stk, int sp) { return (uint32_t)stk[sp * PT_WAVE]; }
+__device__ __forceinline__ void pt_stack_push(PtThreadTag*, int, uint32_t) {}
+__device__ __forceinline__ uint32_t pt_stack_pop(const PtThreadTag*, int) { return 0u; }
+#define PT_STACK_PUSH(stk, sp, val) pt_stack_push((stk), (sp), (uint32_t)(val))
+#define PT_STACK_POP(stk, sp) pt_stack_pop((stk), (sp))
 
 #ifndef PT_WALK_MIN
 #define PT_WALK_MIN 8
@@ -303,6 +314,9 @@ struct PtTraceResult {
  * ray as soon as enough of the wave has finished). */
 template <int MODE, bool COUNT, bool ORIGIN_ZERO, typename StackT, bool SWZ>
 struct PtTraverser {
+  /* the binary32 filter runs wherever the walk is threaded: on the LDS image (SWZ) and on the 32-byte global image */
+  static constexpr bool G32 = !SWZ && std::is_same<StackT, PtThreadTag>::value;
+  static constexpr bool FILT = SWZ || G32;
   V3 o, d, inv; /* SWZ: inv is not kept (the binary64 fallback recomputes 1 / d, the same three divisions) */
   uint32_t dirs;
   bool exact_slab; /* SWZ: also set when the binary32 filter does not apply to this ray (|1/d| >= 2^100) */
@@ -333,7 +347,7 @@ struct PtTraverser {
     /* dirs, shape_tree.ml:201 */
     dirs = (d.x >= 0.0 ? 1u : 0u) | (d.y >= 0.0 ? 2u : 0u) | (d.z >= 0.0 ? 4u : 0u);
     exact_slab = !(pt_isfinite(inv.x) && pt_isfinite(inv.y) && pt_isfinite(inv.z));
-    if (SWZ) {
+    if (FILT) {
       skip_off = 32u + 2u * dirs;
       const double ax = pt_fabs(inv.x), ay = pt_fabs(inv.y), az = pt_fabs(inv.z);
       const double imax = __builtin_fmax(ax, __builtin_fmax(ay, az));
@@ -379,7 +393,7 @@ struct PtTraverser {
     walking = sc.n_nodes > 0;
     leaf_first = 0;
     leaf_n = 0;
-    if (SWZ) update_t32();
+    if (FILT) update_t32();
   }
   /* the closest hit so far as the filter sees it; called whenever r.t may have changed */
   __device__ __forceinline__ void update_t32() {
@@ -395,13 +409,29 @@ struct PtTraverser {
   __device__ __forceinline__ bool test_box(const PtSceneView& sv, uint32_t nd, uint32_t& na, uint32_t& nb, uint32_t& n_real, bool active = true) const {
     const double t_min = 0.0;
     bool hit;
-    if (SWZ) {
-      /* nd is the node's BYTE offset in the binary32 image */
-      const uint4 w0 = *(const uint4*)(sv.swz_nodes + nd), w1 = *(const uint4*)(sv.swz_nodes + nd + 16);
-      na = w1.z & 0xffffu;
-      nb = (w1.z >> 16) | ((w1.w & 3u) << 30);
-      n_real = w1.z >> 16; /* meaningful for leaves only */
-      const float mag = __uint_as_float(w1.w);
+    if (FILT) {
+      uint4 w0, w1;
+      float mag;
+      if (SWZ) { /* nd is the node's BYTE offset in the LDS image */
+        w0 = *(const uint4*)(sv.swz_nodes + nd);
+        w1 = *(const uint4*)(sv.swz_nodes + nd + 16);
+        na = w1.z & 0xffffu;
+        nb = (w1.z >> 16) | ((w1.w & 3u) << 30);
+        n_real = w1.z >> 16; /* meaningful for leaves only */
+        mag = __uint_as_float(w1.w);
+      } else { /* nd is the node's index; 32-byte global image: six binary32 bounds, a, b (leaf b: count | real << 15 | tag) */
+        const uint4* p = (const uint4*)(sv.nodes32 + (size_t)nd * 32u);
+        w0 = p[0];
+        w1 = p[1];
+        na = w1.z;
+        const bool leaf = (w1.w >> 30) == PT_NODE_LEAF_AXIS;
+        n_real = (w1.w >> 15) & 0x7fffu;
+        nb = leaf ? ((w1.w & 0x7fffu) | (PT_NODE_LEAF_AXIS << 30)) : w1.w;
+        /* the node's own magnitude, from the bounds just loaded (the LDS image stores it) */
+        mag = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(__uint_as_float(w0.x)), __builtin_fabsf(__uint_as_float(w0.y))),
+                                              __builtin_fmaxf(__builtin_fabsf(__uint_as_float(w0.z)), __builtin_fabsf(__uint_as_float(w0.w)))),
+                              __builtin_fmaxf(__builtin_fabsf(__uint_as_float(w1.x)), __builtin_fabsf(__uint_as_float(w1.y)))) * 1.000001f;
+      }
       const float t0x = __builtin_fmaf(__uint_as_float(w0.x), fix, fnx), t1x = __builtin_fmaf(__uint_as_float(w0.w), fix, fnx);
       const float t0y = __builtin_fmaf(__uint_as_float(w0.y), fiy, fny), t1y = __builtin_fmaf(__uint_as_float(w1.x), fiy, fny);
       const float t0z = __builtin_fmaf(__uint_as_float(w0.z), fiz, fnz), t1z = __builtin_fmaf(__uint_as_float(w1.y), fiz, fnz);
@@ -417,7 +447,7 @@ struct PtTraverser {
         if (pt_lane() == __ffsll((long long)__ballot(1)) - 1) n_wave_fallbacks++;
 #endif
         if (undecided) { /* the reference's arithmetic, on the binary64 node (global memory: L2-resident, rarely read) */
-          const PtNode* np = sv.nodes + nd / PT_SWZ_NODE_BYTES;
+          const PtNode* np = sv.nodes + (SWZ ? nd / PT_SWZ_NODE_BYTES : nd);
           /* 1 / d again (the same three divisions as Ray.create): opaque to the optimiser, or it hoists them out of the
            * walk and keeps six more registers live across the hot loop for a path taken in 1.6 % of the wave-steps */
           double qx = d.x, qy = d.y, qz = d.z;
@@ -444,7 +474,9 @@ struct PtTraverser {
     bool descend = false;
     uint32_t na, nb, n_real;
     /* threaded image: where to go once this subtree is done (issued beside the node's own reads) */
-    const uint32_t skip = SWZ ? (uint32_t)*(const uint16_t*)(sv.swz_nodes + node + skip_off) : 0u;
+    constexpr bool THREAD32 = !SWZ && std::is_same<StackT, PtThreadTag>::value;
+    const uint32_t skip = SWZ ? (uint32_t)*(const uint16_t*)(sv.swz_nodes + node + skip_off)
+                              : (THREAD32 ? sv.skip32[(size_t)node * 8u + dirs] : 0u);
     const bool hit = test_box(sv, node, na, nb, n_real);
     if (hit) {
       const uint32_t axis = nb >> 30;
@@ -457,7 +489,7 @@ struct PtTraverser {
         /* Branch: near child first (shape_tree.ml:209), far child deferred */
         const uint32_t lhs = na, rhs = nb & 0x3fffffffu;
         const bool lhs_first = (dirs >> axis) & 1u;
-        if (!SWZ) {
+        if (!SWZ && !THREAD32) {
           PT_STACK_PUSH(stack, sp, lhs_first ? rhs : lhs);
           ++sp;
         }
@@ -470,6 +502,9 @@ struct PtTraverser {
        * intersected and r.t shrunk -- the t_max the reference passes to the far child */
       if (SWZ) {
         if (skip == PT_SWZ_END) walking = false;
+        else node = skip;
+      } else if (THREAD32) {
+        if (skip == 0xffffffffu) walking = false;
         else node = skip;
       } else if (sp == 0) walking = false;
       else {
@@ -607,7 +642,7 @@ struct PtTraverser {
       }
     }
     leaf_n = 0;
-    if (SWZ) update_t32();
+    if (FILT) update_t32();
   }
 };
 
@@ -801,6 +836,8 @@ __device__ __forceinline__ PtSceneView pt_scene_view(const PtSceneDev& sc, unsig
   const uint32_t waves_per_block = blockDim.x >> 6;
   PtSceneView sv;
   sv.nodes = sc.nodes;
+  sv.skip32 = sc.node_skip32;
+  sv.nodes32 = (const unsigned char*)sc.nodes32;
   sv.swz_nodes = nullptr;
   sv.sph = sc.sph;
   sv.tri = sc.tri;
@@ -969,8 +1006,8 @@ __global__ __launch_bounds__(PT_TRACE_BLOCK_OF(MODE, LDS_SCENE), (LDS_SCENE && M
   const int lane = pt_lane();
   const int wave_in_block = (int)(threadIdx.x >> 6);
   /* LDS-resident scenes have < 65536 nodes: 16-bit stack entries halve the stack footprint */
-  typedef typename std::conditional<LDS_SCENE, uint16_t, uint32_t>::type StackT;
-  StackT* stack = (StackT*)(lds_raw + (size_t)wave_in_block * PT_WAVE_STACK_BYTES(LDS_SCENE, StackT, stack_depth)) + (LDS_SCENE ? 0 : lane);
+  typedef typename std::conditional<LDS_SCENE, uint16_t, PtThreadTag>::type StackT; /* no per-lane stack anywhere: both walks are threaded */
+  StackT* stack = (StackT*)(lds_raw + (size_t)wave_in_block * PT_WAVE_STACK_BYTES(LDS_SCENE, StackT, stack_depth));
   __shared__ uint32_t lds_chunk_ctr;
   if (threadIdx.x == 0) lds_chunk_ctr = 0u;
   const PtSceneView sv = pt_scene_view<MODE, LDS_SCENE, StackT>(sc, lds_raw, stack_depth);
@@ -1131,8 +1168,8 @@ __global__ __launch_bounds__(PT_TRACE_BLOCK_OF(MODE, LDS_SCENE), PT_TRACE_GLOBAL
   const int lane = pt_lane();
   const int wave_in_block = (int)(threadIdx.x >> 6);
   const uint32_t waves_per_block = blockDim.x >> 6;
-  typedef typename std::conditional<LDS_SCENE, uint16_t, uint32_t>::type StackT;
-  StackT* stack = (StackT*)(lds_raw + (size_t)wave_in_block * PT_WAVE_STACK_BYTES(LDS_SCENE, StackT, stack_depth)) + (LDS_SCENE ? 0 : lane);
+  typedef typename std::conditional<LDS_SCENE, uint16_t, PtThreadTag>::type StackT; /* no per-lane stack anywhere: both walks are threaded */
+  StackT* stack = (StackT*)(lds_raw + (size_t)wave_in_block * PT_WAVE_STACK_BYTES(LDS_SCENE, StackT, stack_depth));
   const PtSceneView sv = pt_scene_view<MODE, LDS_SCENE, StackT>(sc, lds_raw, stack_depth);
   const uint32_t n = *q.count;
   const uint32_t gwave = blockIdx.x * waves_per_block + wave_in_block;
