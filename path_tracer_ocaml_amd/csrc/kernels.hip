@@ -680,7 +680,7 @@ __device__ __forceinline__ PtTraceResult pt_trace_ray(const PtSceneDev& sc, cons
     tr.r.u = tc->u;
     tr.r.v = tc->v;
     tr.r.slot = tc->slot;
-    if (SWZ) tr.update_t32();
+    if (tr.FILT) tr.update_t32(); /* the filter's copy of t: stale, it would pass boxes beyond the restored hit */
   }
   while (valid && (tr.walking || tr.leaf_n > 0)) {
     for (;;) {
@@ -1050,21 +1050,23 @@ __global__ __launch_bounds__(PT_TRACE_BLOCK_OF(MODE, LDS_SCENE), (LDS_SCENE && M
     /* One ray per lane.  TAIL: see PtTailCtl -- a chunk ends when fewer than PT_TAIL_CUT of its rays are still walking;
      * their states (16 bytes each) go to this wave's list in `susp` and once 64 - PT_TAIL_CUT have gathered the wave walks
      * them as a chunk of their own.  tools/sim_coherence.py: 0.527 -> 0.435 wave steps per ray at 16. */
-    constexpr bool TAIL = PT_TAIL_CUT > 0 && LDS_SCENE && !PRIMARY && PT_DIAG == 0;
+    constexpr bool TAIL = PT_TAIL_CUT > 0 && PT_DIAG == 0; /* both walks are threaded (LDS image, HBM / L2); a parked camera ray is recomputed from its index */
     constexpr bool TAIL_UV = TAIL && MODE == PT_MODE_ARRAY; /* triangle hits carry barycentrics: a second 16 bytes per state */
-    uint4* my_susp = TAIL ? susp + ((size_t)blockIdx.x * (blockDim.x >> 6) + wave_in_block) * (PT_WAVE * 2) : nullptr;
+    constexpr bool TAIL_W = TAIL && !LDS_SCENE;            /* 32-bit node index and slot: a third 16 bytes */
+    uint4* my_susp = TAIL ? susp + ((size_t)blockIdx.x * (blockDim.x >> 6) + wave_in_block) * (PT_WAVE * 3) : nullptr;
     uint32_t n_susp = 0; /* wave-uniform */
     bool more = true;
     for (;;) { /* no `continue` past a point where lanes have diverged: take() is wave-uniform */
       bool resume = false, valid = false;
       uint32_t i = 0;
-      uint4 parked = make_uint4(0, 0, 0, 0), parked_uv = make_uint4(0, 0, 0, 0);
+      uint4 parked = make_uint4(0, 0, 0, 0), parked_uv = make_uint4(0, 0, 0, 0), parked_w = make_uint4(0, 0, 0, 0);
       if (TAIL && (n_susp > (uint32_t)(PT_WAVE - PT_TAIL_CUT) || (!more && n_susp > 0))) {
         resume = true;
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); /* this wave's own parked states, written below */
         valid = (uint32_t)lane < n_susp;
         if (valid) parked = my_susp[lane];
         if (TAIL_UV && valid) parked_uv = my_susp[PT_WAVE + lane];
+        if (TAIL_W && valid) parked_w = my_susp[2 * PT_WAVE + lane];
         i = parked.x;
         n_susp = 0;
       } else {
@@ -1091,8 +1093,8 @@ __global__ __launch_bounds__(PT_TRACE_BLOCK_OF(MODE, LDS_SCENE), (LDS_SCENE && M
       PtTailCtl tc;
       tc.min_active = (TAIL && more) ? PT_TAIL_CUT : 0; /* the last chunks of a wave run to completion */
       tc.resume = resume && valid;
-      tc.node = parked.y & 0xffffu;
-      tc.slot = (int)(parked.y >> 16) == 0xffff ? -1 : (int)(parked.y >> 16);
+      tc.node = TAIL_W ? parked_w.x : (parked.y & 0xffffu);
+      tc.slot = TAIL_W ? (int)parked_w.y : ((int)(parked.y >> 16) == 0xffff ? -1 : (int)(parked.y >> 16));
       tc.t = __hiloint2double((int)parked.w, (int)parked.z);
       tc.u = __hiloint2double((int)parked_uv.y, (int)parked_uv.x);
       tc.v = __hiloint2double((int)parked_uv.w, (int)parked_uv.z);
@@ -1124,6 +1126,7 @@ __global__ __launch_bounds__(PT_TRACE_BLOCK_OF(MODE, LDS_SCENE), (LDS_SCENE && M
             const uint32_t k = n_susp + (uint32_t)__popcll(pm & ((1ull << lane) - 1ull));
             my_susp[k] = make_uint4(i, tc.node | ((uint32_t)(r.slot < 0 ? 0xffff : r.slot) << 16),
                                     (uint32_t)__double2loint(r.t), (uint32_t)__double2hiint(r.t));
+            if (TAIL_W) my_susp[2 * PT_WAVE + k] = make_uint4(tc.node, (uint32_t)r.slot, 0u, 0u);
             if (TAIL_UV)
               my_susp[PT_WAVE + k] = make_uint4((uint32_t)__double2loint(r.u), (uint32_t)__double2hiint(r.u), (uint32_t)__double2loint(r.v), (uint32_t)__double2hiint(r.v));
           }
