@@ -22,14 +22,19 @@
 #define PT_WAVE 64
 
 /* ------------------------------------------------------------------ path queue (SoA in HBM) */
+/* A queue entry is two records: the ray (what k_trace reads, densely) and the rest of the path's state (what only the shade
+ * stage reads, entry by entry in the order its category pools dictate -- one 32-byte sector instead of five 8-byte fields in
+ * five different sectors).  Both are multiples of 16 bytes: every access is a 16-byte load or store. */
+struct PtRayRec { double ox, oy, oz, dx, dy, dz; };                  /* 48 B: ray origin, direction */
+struct PtPathRec { double ar, ag, ab; uint32_t id; int32_t offset; }; /* 32 B: attn0 (integrator.ml:30); slot in the batch's
+                                                                         contribution buffer; sampler offset = gy*W + gx + pass*spp
+                                                                         (integrator.ml:98) */
+struct PtEmitRec { double er, eg, eb, pad; };                         /* 32 B: emit0; only allocated / touched when the scene has emitters */
 struct PtQueue {
-  double *ox, *oy, *oz; /* ray origin */
-  double *dx, *dy, *dz; /* ray direction */
-  double *ar, *ag, *ab; /* attn0 (integrator.ml:30) */
-  double *er, *eg, *eb; /* emit0; only allocated / touched when the scene has emitters */
-  uint32_t* id;         /* slot in the batch's contribution buffer */
-  int32_t* offset;      /* sampler offset = gy*W + gx + pass*spp (integrator.ml:98) */
-  uint32_t* count;      /* number of live entries (device) */
+  PtRayRec* ray;
+  PtPathRec* path;
+  PtEmitRec* emit;
+  uint32_t* count; /* number of live entries (device) */
 };
 
 struct PtHits {
@@ -37,6 +42,49 @@ struct PtHits {
   int32_t* slot; /* leaf slot index, -1 = miss; >= n_slots = floor triangle */
   double *u, *v; /* triangle barycentrics (triangle.ml:14-20); only with triangles */
 };
+
+/* A queue written by k_shade_pool has HOLES (unused entries of its last blocks): direction x = a NaN whose payload no
+ * arithmetic produces.  k_trace skips a hole and records PT_SLOT_HOLE for it. */
+#define PT_HOLE_HI 0x7ff8dead
+#define PT_SLOT_HOLE (-2)
+__device__ __forceinline__ bool pt_is_hole(double dx) { return __double2hiint(dx) == (int)PT_HOLE_HI; }
+
+__device__ __forceinline__ void pt_q_load_ray(const PtQueue& q, uint32_t i, V3& o, V3& d) {
+  const double2* r = (const double2*)(q.ray + i);
+  const double2 a = r[0], b = r[1], c = r[2];
+  o = v3(a.x, a.y, b.x);
+  d = v3(b.y, c.x, c.y);
+}
+__device__ __forceinline__ void pt_q_load_path(const PtQueue& q, uint32_t i, V3& attn, uint32_t& id, int& offset) {
+  const double2* r = (const double2*)(q.path + i);
+  const double2 a = r[0], b = r[1];
+  attn = v3(a.x, a.y, b.x);
+  id = (uint32_t)__double2loint(b.y);
+  offset = __double2hiint(b.y);
+}
+__device__ __forceinline__ V3 pt_q_load_emit(const PtQueue& q, uint32_t i) {
+  const double2* r = (const double2*)(q.emit + i);
+  const double2 a = r[0], b = r[1];
+  return v3(a.x, a.y, b.x);
+}
+__device__ __forceinline__ void pt_q_store_ray(const PtQueue& q, uint32_t i, V3 o, V3 d) {
+  double2* r = (double2*)(q.ray + i);
+  r[0] = make_double2(o.x, o.y);
+  r[1] = make_double2(o.z, d.x);
+  r[2] = make_double2(d.y, d.z);
+}
+template <bool EMIT>
+__device__ __forceinline__ void pt_q_store(const PtQueue& q, uint32_t i, V3 o, V3 d, V3 attn, V3 emit, uint32_t id, int offset) {
+  pt_q_store_ray(q, i, o, d);
+  double2* r = (double2*)(q.path + i);
+  r[0] = make_double2(attn.x, attn.y);
+  r[1] = make_double2(attn.z, __hiloint2double(offset, (int)id));
+  if (EMIT) {
+    double2* e = (double2*)(q.emit + i);
+    e[0] = make_double2(emit.x, emit.y);
+    e[1] = make_double2(emit.z, 0.0);
+  }
+}
 
 struct PtCounters { /* device-side work counters (count_work) */
   unsigned long long segments, nodes, prims, floor;
@@ -108,12 +156,8 @@ __global__ __launch_bounds__(256) void k_generate_list(PtSceneDev sc, int width,
   const double cx = ((double)x + dxs) * widthf;
   const double cy = 1.0 - (((double)gy + dys) * heightf);
   const V3 dir = pt_camera_dir(sc, cx, cy);
-  q.ox[dst] = 0.0; q.oy[dst] = 0.0; q.oz[dst] = 0.0;
-  q.dx[dst] = dir.x; q.dy[dst] = dir.y; q.dz[dst] = dir.z;
-  q.ar[dst] = 1.0; q.ag[dst] = 1.0; q.ab[dst] = 1.0;
-  if (sc.has_emit) { q.er[dst] = 0.0; q.eg[dst] = 0.0; q.eb[dst] = 0.0; }
-  q.id[dst] = (uint32_t)i;
-  q.offset[dst] = offset;
+  if (sc.has_emit) pt_q_store<true>(q, dst, v3(0.0, 0.0, 0.0), dir, v3(1.0, 1.0, 1.0), v3(0.0, 0.0, 0.0), (uint32_t)i, offset);
+  else pt_q_store<false>(q, dst, v3(0.0, 0.0, 0.0), dir, v3(1.0, 1.0, 1.0), v3(0.0, 0.0, 0.0), (uint32_t)i, offset);
 }
 
 /* ------------------------------------------------------------------ trace */
@@ -1031,8 +1075,13 @@ __global__ __launch_bounds__(PT_TRACE_BLOCK_OF(MODE, LDS_SCENE), (LDS_SCENE && M
           valid = ps.valid;
           if (valid) d = pt_primary_dir(sc, g, ps, alpha);
         } else {
-          o = v3(q.ox[i], q.oy[i], q.oz[i]);
-          d = v3(q.dx[i], q.dy[i], q.dz[i]);
+          pt_q_load_ray(q, i, o, d);
+          if (pt_is_hole(d.x)) {
+            valid = false;
+            hits.slot[i] = PT_SLOT_HOLE;
+            o = v3(0.0, 0.0, 0.0);
+            d = v3(0.0, 0.0, -1.0);
+          }
         }
       }
       if (COUNT && valid) c_seg++;
@@ -1084,8 +1133,13 @@ __global__ __launch_bounds__(PT_TRACE_BLOCK_OF(MODE, LDS_SCENE), (LDS_SCENE && M
           valid = ps.valid;
           if (valid) d = pt_primary_dir(sc, g, ps, alpha);
         } else {
-          o = v3(q.ox[i], q.oy[i], q.oz[i]);
-          d = v3(q.dx[i], q.dy[i], q.dz[i]);
+          pt_q_load_ray(q, i, o, d);
+          if (pt_is_hole(d.x)) { /* never parked, so never seen on resume */
+            valid = false;
+            hits.slot[i] = PT_SLOT_HOLE;
+            o = v3(0.0, 0.0, 0.0);
+            d = v3(0.0, 0.0, -1.0);
+          }
         }
       }
       if (COUNT && valid && !resume) c_seg++;
@@ -1211,7 +1265,9 @@ __global__ __launch_bounds__(PT_TRACE_BLOCK_OF(MODE, LDS_SCENE), PT_TRACE_GLOBAL
         if (p < my_positions && i < n) {
           ray = i;
           if (COUNT) c_seg++;
-          tr.begin(sc, sv, v3(q.ox[i], q.oy[i], q.oz[i]), v3(q.dx[i], q.dy[i], q.dz[i]), c_floor);
+          V3 ro, rd;
+          pt_q_load_ray(q, i, ro, rd);
+          tr.begin(sc, sv, ro, rd, c_floor);
         }
       }
       pos += (uint32_t)__popcll(im);
@@ -1485,7 +1541,7 @@ __device__ __forceinline__ int pt_bin_key(const PtSceneDev& sc, V3 d) {
   return (d.x >= 0.0 ? 1 : 0) | (d.y >= 0.0 ? 2 : 0) | (d.z >= 0.0 ? 4 : 0);
 }
 template <bool TRAILING_SYNC>
-__device__ __forceinline__ uint32_t pt_block_append_binned(uint32_t* counter, bool keep, int key, uint32_t* lds) {
+__device__ __forceinline__ uint32_t pt_block_append_binned(uint32_t* counter, bool keep, int key, uint32_t* lds, unsigned long long* tm_first_barrier = nullptr) {
   const int lane = pt_lane();
   const int wave = (int)(threadIdx.x >> 6), nw = (int)(blockDim.x >> 6);
   uint32_t rank = 0;
@@ -1495,7 +1551,9 @@ __device__ __forceinline__ uint32_t pt_block_append_binned(uint32_t* counter, bo
     if (key == k) rank = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
     if (lane == 0) lds[k * nw + wave] = (uint32_t)__popcll(m);
   }
+  const unsigned long long tm0 = tm_first_barrier ? __builtin_readcyclecounter() : 0ull;
   __syncthreads();
+  if (tm_first_barrier) *tm_first_barrier += __builtin_readcyclecounter() - tm0; /* diagnostic builds: waiting for the window's slowest wave */
   if (wave == 0) {
     const int entries = PT_APPEND_BINS * nw; /* <= 64 */
     const uint32_t v = lane < entries ? lds[lane] : 0u;
@@ -1588,12 +1646,9 @@ __device__ __forceinline__ void pt_shade_entry(const PtSceneDev& sc, const PtQue
         id = ps.id;
         offset = ps.offset;
       } else {
-        o = v3(q.ox[i], q.oy[i], q.oz[i]);
-        d = v3(q.dx[i], q.dy[i], q.dz[i]);
-        attn0 = v3(q.ar[i], q.ag[i], q.ab[i]);
-        if (EMIT) emit0 = v3(q.er[i], q.eg[i], q.eb[i]);
-        id = q.id[i];
-        offset = q.offset[i];
+        pt_q_load_ray(q, i, o, d);
+        pt_q_load_path(q, i, attn0, id, offset);
+        if (EMIT) emit0 = pt_q_load_emit(q, i);
       }
       const int slot = CAT == PT_CAT_MISS ? -1 : hits.slot[i];
       V3 result = v3(0, 0, 0);
@@ -1676,6 +1731,9 @@ __device__ __forceinline__ void pt_shade_entry(const PtSceneDev& sc, const PtQue
 #ifndef PT_SHADE_WAVES
 #define PT_SHADE_WAVES 4
 #endif
+#ifndef PT_SHADE_TIMING
+#define PT_SHADE_TIMING 0
+#endif
 template <bool EMIT, bool PRIMARY>
 __global__ __launch_bounds__(PT_SHADE_BLOCK, PT_SHADE_WAVES) void k_shade(PtSceneDev sc, PtQueue q, PtHits hits, PtQueue out, PtContrib contrib,
                                                 const double* __restrict__ alpha, int bounce, int last_bounce,
@@ -1723,7 +1781,18 @@ __global__ __launch_bounds__(PT_SHADE_BLOCK, PT_SHADE_WAVES) void k_shade(PtScen
     }
     if (bB != 0xffffffffu && bB + threadIdx.x < n) pf_slot = hits.slot[bB + threadIdx.x];
   }
+#if PT_SHADE_TIMING
+  /* diagnostic build (tools/shade_timing.sh): where a wave's life goes, in shader clocks, summed per bounce into work[16..] */
+  unsigned long long tm_sort = 0, tm_entry = 0, tm_append = 0, tm_store = 0, tm_wait = 0;
+  const unsigned long long tm_begin = __builtin_readcyclecounter();
+#define PT_TM(var, since) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long now_ = __builtin_readcyclecounter(); var += now_ - since; since = now_; __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define PT_TM(var, since) do { } while (0)
+#endif
   for (int it = 0; wA < win_limit; ++it) {
+#if PT_SHADE_TIMING
+    unsigned long long tm_t = __builtin_readcyclecounter();
+#endif
     const uint32_t base_i = PT_WIN_BASE(wA);
     /* the window after wC: broadcast what thread 0 fetched an iteration ago, fetch the one after it */
 #if PT_DYNAMIC_WINDOWS
@@ -1747,8 +1816,10 @@ __global__ __launch_bounds__(PT_SHADE_BLOCK, PT_SHADE_WAVES) void k_shade(PtScen
       }
       i = base_i + pt_block_sort_by_category(key, lds_cnt, lds_perm);
     }
+    PT_TM(tm_sort, tm_t);
     PtShadeOut so;
     pt_shade_entry<EMIT, PRIMARY, PT_CAT_NONE>(sc, q, hits, contrib, alpha, bounce, last_bounce, g, i, i < n, so);
+    PT_TM(tm_entry, tm_t);
     const bool keep = so.keep;
     const V3 n_o = so.n_o, n_d = so.n_d, n_attn = so.n_attn, n_emit = so.n_emit;
     const uint32_t id = so.id;
@@ -1756,18 +1827,17 @@ __global__ __launch_bounds__(PT_SHADE_BLOCK, PT_SHADE_WAVES) void k_shade(PtScen
 #if PT_APPEND_BINS > 1
     const int octant = pt_bin_key(sc, n_d);
     /* with the category sort on, its three barriers separate one append from the next */
+#if PT_SHADE_TIMING
+    const uint32_t dst = pt_block_append_binned<!(PT_SHADE_SORT && !PRIMARY)>(out.count, keep, octant, lds_bins, &tm_wait);
+#else
     const uint32_t dst = pt_block_append_binned<!(PT_SHADE_SORT && !PRIMARY)>(out.count, keep, octant, lds_bins);
+#endif
 #else
     const uint32_t dst = pt_block_append(out.count, keep, lds_append);
 #endif
-    if (keep) {
-      out.ox[dst] = n_o.x; out.oy[dst] = n_o.y; out.oz[dst] = n_o.z;
-      out.dx[dst] = n_d.x; out.dy[dst] = n_d.y; out.dz[dst] = n_d.z;
-      out.ar[dst] = n_attn.x; out.ag[dst] = n_attn.y; out.ab[dst] = n_attn.z;
-      if (EMIT) { out.er[dst] = n_emit.x; out.eg[dst] = n_emit.y; out.eb[dst] = n_emit.z; }
-      out.id[dst] = id;
-      out.offset[dst] = offset;
-    }
+    PT_TM(tm_append, tm_t);
+    if (keep) pt_q_store<EMIT>(out, dst, n_o, n_d, n_attn, n_emit, id, offset);
+    PT_TM(tm_store, tm_t);
     /* every path through the append above crossed a workgroup barrier after thread 0's store to lds_win[it & 1],
      * and the next store to that word is two iterations away */
     wA = wB;
@@ -1779,6 +1849,252 @@ __global__ __launch_bounds__(PT_SHADE_BLOCK, PT_SHADE_WAVES) void k_shade(PtScen
 #endif
   }
 #undef PT_WIN_BASE
+#if PT_SHADE_TIMING
+  if (pt_lane() == 0) {
+    const unsigned long long life = __builtin_readcyclecounter() - tm_begin;
+    atomicAdd(work + 16, (uint32_t)(tm_sort >> 8));
+    atomicAdd(work + 17, (uint32_t)(tm_entry >> 8));
+    atomicAdd(work + 18, (uint32_t)(tm_append >> 8));
+    atomicAdd(work + 19, (uint32_t)(tm_store >> 8));
+    atomicAdd(work + 20, (uint32_t)(life >> 8));
+    atomicAdd(work + 21, 1u);
+    atomicAdd(work + 22, (uint32_t)(tm_wait >> 8));
+  }
+#endif
+#undef PT_TM
+}
+
+/* ------------------------------------------------------------------ the shade stage without workgroup barriers
+ * k_shade above sorts a 512-entry window by category and appends its survivors with one atomic: both need workgroup
+ * barriers, and between two barriers the window's waves run materials of very different length (a miss is ~150
+ * instructions, a checker Lambertian ~1200).  Measured with the kernel's own clock (tools/shade_timing.sh, bounce 1 of the
+ * headline frame): 33 % of a wave's life is spent at the append's first barrier waiting for the window's slowest wave,
+ * 10 % behind the append's atomic, 12 % in the sort, 39 % in the segment's arithmetic.
+ *
+ * Here a wave never waits for another one (except while a full output block is being replaced, below):
+ *  - POOLS.  Every wave owns one list of queue indices per category in LDS (128 entries each).  It classifies raw chunks of 64
+ *    entries (hit slot -> category) into its lists and, whenever a list holds 64, shades those 64 together: one category per
+ *    wave step by construction, no sort.  When the input is exhausted the lists are drained (the only partly filled steps).
+ *  - BLOCKED OUTPUT.  The workgroup owns one output block of PT_POOL_BLOCK entries per bin (pt_bin_key: elevation / octant);
+ *    a wave reserves room for its survivors of a bin with ONE LDS atomic on a word that holds (block, cursor) together, so the
+ *    block it writes to is the one its reservation belongs to.  The wave whose reservation crosses the end of the block fills
+ *    it up, gets the next block from the queue's global counter (one device atomic per PT_POOL_BLOCK survivors, as few as the
+ *    windowed append) and publishes it; waves that arrive in between spin on the LDS word.  A block is single-bin, so every
+ *    wave of the next trace launch walks rays of one bin.
+ *  - HOLES.  When the kernel ends the blocks in use are partly filled.  The last wave of the workgroup marks the unused
+ *    entries by a direction whose x is a NaN with a payload no arithmetic produces (PT_HOLE_HI); k_trace skips such an entry and
+ *    records slot PT_SLOT_HOLE for it, which the next launch of this kernel drops when it classifies.  The queue's count
+ *    is then a number of ENTRIES (a multiple of the block), not of rays; the segment counters count rays.
+ * Every ray still gets exactly pt_shade_entry's arithmetic; the order of the queue changes, which no result depends on
+ * (contributions are stored per path id and summed in pass order). */
+#define PT_N_SHADE_CAT 5 /* PT_CAT_MISS .. PT_CAT_DIELECTRIC */
+#ifndef PT_POOL_BLOCK
+#define PT_POOL_BLOCK 256 /* < 4096 - 16 * 64: the cursor field must hold a full block plus one stray reservation per wave */
+#endif
+#ifndef PT_POOL_RUN
+#define PT_POOL_RUN 32 /* a workgroup's share of the input: runs of this many consecutive chunks, dealt round-robin; its waves take
+                          the chunks of a run one by one (LDS counter), so they shade neighbouring chunks at the same time and a block of
+                          survivors holds rays that were neighbours -- the next trace launch walks them together (single chunks dealt
+                          round-robin cost that launch 8 %).  Runs handed to single waves from device counters: shade +18 %. */
+#endif
+#ifndef PT_POOL_MIN_CHUNKS
+#define PT_POOL_MIN_CHUNKS 16 /* raw chunks per wave below which fewer workgroups take part (the drain costs up to 5 part-filled steps) */
+#endif
+#define PT_POOL_NO_BLOCK 0xfffffu
+
+template <bool EMIT>
+__device__ __forceinline__ void pt_pool_push(const PtSceneDev& sc, const PtQueue& out, const PtShadeOut& so, uint32_t* lds_out) {
+  const int lane = pt_lane();
+  const int bin = pt_bin_key(sc, so.n_d);
+  if (__ballot(so.keep) == 0) return;
+  /* all bins at once: lane b < 8 holds bin b's survivor count and makes its reservation -- one LDS atomic instruction */
+  uint32_t rank = 0, kk = 0;
+#pragma unroll
+  for (int b = 0; b < PT_APPEND_BINS; ++b) {
+    const unsigned long long m = __ballot(so.keep && bin == b);
+    if (bin == b) rank = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+    if (lane == b) kk = (uint32_t)__popcll(m);
+  }
+  uint32_t st = 0;
+  if (kk != 0) st = __hip_atomic_fetch_add(lds_out + lane, kk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  /* a reservation that does not fit its block (pos + k > PT_POOL_BLOCK): rare, one bin at a time, wave-uniform */
+  unsigned long long slow = __ballot(kk != 0 && (st & 0xfffu) + kk > (uint32_t)PT_POOL_BLOCK);
+  uint32_t blk2 = 0, head = 0xffffffffu; /* lane b: the second block of a reservation that crossed into it, and how much went to the first */
+  while (slow != 0) {
+    const int b = __ffsll((long long)slow) - 1;
+    slow &= slow - 1;
+    const uint32_t k = (uint32_t)__builtin_amdgcn_readlane((int)kk, b);
+    uint32_t sb = (uint32_t)__builtin_amdgcn_readlane((int)st, b);
+    for (;;) {
+      const uint32_t pos = sb & 0xfffu, blk = sb >> 12;
+      if (pos + k <= (uint32_t)PT_POOL_BLOCK) break; /* a retry that fits */
+      if (pos <= (uint32_t)PT_POOL_BLOCK) {
+        /* this reservation crosses the end of the block (or finds it exactly full, or finds no block yet): fill it up and
+         * bring the next one.  Everybody else sees pos > PT_POOL_BLOCK until the new word is stored. */
+        uint32_t nb = 0;
+        if (lane == 0) nb = atomicAdd(out.count, (uint32_t)PT_POOL_BLOCK) / (uint32_t)PT_POOL_BLOCK;
+        nb = (uint32_t)__builtin_amdgcn_readfirstlane((int)nb);
+        const uint32_t h = (uint32_t)PT_POOL_BLOCK - pos;
+        if (lane == 0) __hip_atomic_store(lds_out + b, (nb << 12) | (k - h), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (lane == b) { blk2 = nb; head = h; }
+        break;
+      }
+      /* the block is being replaced by another wave: wait for the new one, reserve again */
+      uint32_t cur;
+      do {
+        __builtin_amdgcn_s_sleep(2);
+        cur = __hip_atomic_load(lds_out + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      } while ((cur >> 12) == blk);
+      uint32_t again = 0;
+      if (lane == 0) again = __hip_atomic_fetch_add(lds_out + b, k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      sb = (uint32_t)__builtin_amdgcn_readfirstlane((int)again);
+    }
+    if (lane == b) st = sb;
+  }
+  /* every lane picks up its bin's reservation */
+  const uint32_t my_st = (uint32_t)__shfl((int)st, bin, 64);
+  const uint32_t my_head = (uint32_t)__shfl((int)head, bin, 64);
+  const uint32_t my_blk2 = (uint32_t)__shfl((int)blk2, bin, 64);
+  if (so.keep) {
+    const uint32_t dst = rank < my_head ? (my_st >> 12) * (uint32_t)PT_POOL_BLOCK + (my_st & 0xfffu) + rank
+                                        : my_blk2 * (uint32_t)PT_POOL_BLOCK + (rank - my_head);
+    pt_q_store<EMIT>(out, dst, so.n_o, so.n_d, so.n_attn, so.n_emit, so.id, so.offset);
+  }
+}
+
+template <bool EMIT, bool PRIMARY>
+__global__ __launch_bounds__(PT_SHADE_BLOCK, PT_SHADE_WAVES) void k_shade_pool(PtSceneDev sc, PtQueue q, PtHits hits, PtQueue out, PtContrib contrib,
+                                                const double* __restrict__ alpha, int bounce, int last_bounce,
+                                                PtGenParams g, uint32_t n_primary, uint32_t* work) {
+  __shared__ uint32_t lds_pool[PT_SHADE_BLOCK / 64][PT_N_SHADE_CAT][128];
+  __shared__ uint32_t lds_out[PT_APPEND_BINS];
+  __shared__ uint32_t lds_chunk_ctr, lds_done;
+  const int lane = pt_lane(), wave = (int)(threadIdx.x >> 6), nw = (int)(blockDim.x >> 6);
+  const uint32_t n = PRIMARY ? n_primary : *q.count;
+  const uint32_t total_chunks = (uint32_t)(((unsigned long long)n + PT_WAVE - 1) / PT_WAVE);
+  uint32_t n_wg = total_chunks / (uint32_t)(PT_POOL_MIN_CHUNKS * nw);
+  n_wg = n_wg < 1u ? 1u : (n_wg > gridDim.x ? gridDim.x : n_wg);
+  if (blockIdx.x >= n_wg) return; /* workgroup-uniform */
+  if (threadIdx.x == 0) { lds_chunk_ctr = 0u; lds_done = 0u; }
+  if (threadIdx.x < PT_APPEND_BINS) lds_out[threadIdx.x] = (PT_POOL_NO_BLOCK << 12) | (uint32_t)PT_POOL_BLOCK; /* "full": the first push brings a block */
+  __syncthreads(); /* the only workgroup barrier */
+  uint32_t (*pool)[128] = lds_pool[wave];
+  uint32_t cnt[PT_N_SHADE_CAT];
+#pragma unroll
+  for (int k = 0; k < PT_N_SHADE_CAT; ++k) cnt[k] = 0u;
+  /* raw chunks are classified through a two-stage pipeline, so that neither of the two dependent loads (hit slot, then the
+   * slot's category) is waited for: stage B holds a chunk whose slots are on their way, stage C one whose categories are */
+  uint32_t iB = 0u, iC = 0u;
+  int slotB = PT_SLOT_HOLE, catC = PT_CAT_NONE;
+  bool haveB = false, haveC = false; /* wave-uniform */
+#define PT_POOL_TAKE_B() do { \
+    uint32_t unit_ = 0u; \
+    if (lane == 0) unit_ = __hip_atomic_fetch_add(&lds_chunk_ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); \
+    unit_ = (uint32_t)__builtin_amdgcn_readfirstlane((int)unit_); \
+    unit_ = (unit_ / PT_POOL_RUN) * (n_wg * PT_POOL_RUN) + blockIdx.x * PT_POOL_RUN + (unit_ % PT_POOL_RUN); \
+    haveB = unit_ < total_chunks; \
+    iB = unit_ * PT_WAVE + (uint32_t)lane; \
+    slotB = PT_SLOT_HOLE; \
+    if (haveB) { \
+      bool valid_ = iB < n; \
+      if (PRIMARY && valid_) valid_ = pt_primary_decode(g, iB).valid; \
+      if (valid_) slotB = hits.slot[iB]; \
+    } \
+  } while (0)
+#define PT_POOL_ADVANCE() do { \
+    iC = iB; haveC = haveB; \
+    catC = slotB == PT_SLOT_HOLE ? PT_CAT_NONE : (slotB < 0 ? PT_CAT_MISS : (int)sc.slot_cat[slotB]); \
+    PT_POOL_TAKE_B(); \
+  } while (0)
+  PT_POOL_TAKE_B();
+  PT_POOL_ADVANCE();
+  bool more = haveC;
+#if PT_SHADE_TIMING
+  unsigned long long tm_refill = 0, tm_entry = 0, tm_push = 0, tm_steps = 0, tm_live = 0;
+  const unsigned long long tm_begin = __builtin_readcyclecounter();
+  unsigned long long tm_t = tm_begin;
+#define PT_TM(var, since) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long now_ = __builtin_readcyclecounter(); var += now_ - since; since = now_; __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define PT_TM(var, since) do { } while (0)
+#endif
+  for (;;) {
+    /* the fullest list that holds a whole step; once the input is exhausted, the fullest list */
+    int c = -1;
+    uint32_t best = more ? (uint32_t)(PT_WAVE - 1) : 0u;
+#pragma unroll
+    for (int k = 0; k < PT_N_SHADE_CAT; ++k)
+      if (cnt[k] > best) { best = cnt[k]; c = k; }
+    if (c >= 0) {
+      const uint32_t take = best < (uint32_t)PT_WAVE ? best : (uint32_t)PT_WAVE;
+      const uint32_t start = best - take;
+      const bool live = (uint32_t)lane < take;
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); /* this wave's own pushes below */
+      uint32_t i = 0u;
+      PtShadeOut so;
+      so.keep = false;
+#pragma unroll
+      for (int k = 0; k < PT_N_SHADE_CAT; ++k) {
+        if (c == k) { /* wave-uniform */
+          cnt[k] = start;
+          if (live) i = pool[k][start + lane];
+          if (k == PT_CAT_MISS) pt_shade_entry<EMIT, PRIMARY, PT_CAT_MISS>(sc, q, hits, contrib, alpha, bounce, last_bounce, g, i, live, so);
+          if (k == PT_CAT_LAMBERT_SOLID) pt_shade_entry<EMIT, PRIMARY, PT_CAT_LAMBERT_SOLID>(sc, q, hits, contrib, alpha, bounce, last_bounce, g, i, live, so);
+          if (k == PT_CAT_LAMBERT_CHECKER) pt_shade_entry<EMIT, PRIMARY, PT_CAT_LAMBERT_CHECKER>(sc, q, hits, contrib, alpha, bounce, last_bounce, g, i, live, so);
+          if (k == PT_CAT_METAL) pt_shade_entry<EMIT, PRIMARY, PT_CAT_METAL>(sc, q, hits, contrib, alpha, bounce, last_bounce, g, i, live, so);
+          if (k == PT_CAT_DIELECTRIC) pt_shade_entry<EMIT, PRIMARY, PT_CAT_DIELECTRIC>(sc, q, hits, contrib, alpha, bounce, last_bounce, g, i, live, so);
+        }
+      }
+      PT_TM(tm_entry, tm_t);
+      if (c != PT_CAT_MISS && !last_bounce) pt_pool_push<EMIT>(sc, out, so, lds_out);
+      PT_TM(tm_push, tm_t);
+#if PT_SHADE_TIMING
+      tm_steps++;
+      tm_live += take;
+#endif
+      continue;
+    }
+    if (!more) break;
+#pragma unroll
+    for (int k = 0; k < PT_N_SHADE_CAT; ++k) {
+      const unsigned long long m = __ballot(catC == k);
+      if (catC == k) pool[k][cnt[k] + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = iC;
+      cnt[k] += (uint32_t)__popcll(m);
+    }
+    PT_POOL_ADVANCE();
+    more = haveC;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    PT_TM(tm_refill, tm_t);
+  }
+#if PT_SHADE_TIMING
+  if (lane == 0) {
+    uint32_t* tw = work + 16; /* diagnostic build only */
+    const unsigned long long life = __builtin_readcyclecounter() - tm_begin;
+    atomicAdd(tw + 0, (uint32_t)(tm_refill >> 8));
+    atomicAdd(tw + 1, (uint32_t)(tm_entry >> 8));
+    atomicAdd(tw + 2, (uint32_t)(tm_push >> 8));
+    atomicAdd(tw + 3, (uint32_t)tm_steps);
+    atomicAdd(tw + 4, (uint32_t)(life >> 8));
+    atomicAdd(tw + 5, 1u);
+    atomicAdd(tw + 6, (uint32_t)tm_live);
+    atomicMax(tw + 7, (uint32_t)(life >> 8));
+  }
+#endif
+#undef PT_TM
+#undef PT_POOL_TAKE_B
+#undef PT_POOL_ADVANCE
+  if (last_bounce) return;
+  /* the workgroup's last wave marks what is left of its blocks as holes */
+  uint32_t done = 0u;
+  if (lane == 0) done = __hip_atomic_fetch_add(&lds_done, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
+  done = (uint32_t)__builtin_amdgcn_readfirstlane((int)done);
+  if (done != (uint32_t)(nw - 1)) return;
+  for (int b = 0; b < PT_APPEND_BINS; ++b) {
+    const uint32_t st = __hip_atomic_load(lds_out + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    const uint32_t blk = st >> 12, pos = st & 0xfffu;
+    if (blk == PT_POOL_NO_BLOCK) continue;
+    for (uint32_t e = pos + (uint32_t)lane; e < (uint32_t)PT_POOL_BLOCK; e += PT_WAVE)
+      out.ray[(size_t)blk * PT_POOL_BLOCK + e].dx = __hiloint2double((int)PT_HOLE_HI, 0);
+  }
 }
 
 /* ------------------------------------------------------------------ per-stage queues for the shade stage
@@ -1794,7 +2110,6 @@ struct PtCatLists {
   uint32_t* count;    /* PT_N_SHADE_CAT list lengths (device, zero at launch) */
   size_t cap;
 };
-#define PT_N_SHADE_CAT 5 /* PT_CAT_MISS .. PT_CAT_DIELECTRIC */
 #define PT_CLASSIFY_BLOCK 1024
 #define PT_CLASSIFY_ROWS 4 /* entries per thread per iteration: 4096 entries, 5 atomics */
 
@@ -1895,14 +2210,7 @@ __global__ __launch_bounds__(PT_SHADE_BLOCK, PT_SHADE_CAT_WAVES) void k_shade_ca
     if (CAT != PT_CAT_MISS) {
       const int octant = pt_bin_key(sc, so.n_d);
       const uint32_t dst = pt_block_append_binned<true>(out.count, so.keep, octant, lds_bins);
-      if (so.keep) {
-        out.ox[dst] = so.n_o.x; out.oy[dst] = so.n_o.y; out.oz[dst] = so.n_o.z;
-        out.dx[dst] = so.n_d.x; out.dy[dst] = so.n_d.y; out.dz[dst] = so.n_d.z;
-        out.ar[dst] = so.n_attn.x; out.ag[dst] = so.n_attn.y; out.ab[dst] = so.n_attn.z;
-        if (EMIT) { out.er[dst] = so.n_emit.x; out.eg[dst] = so.n_emit.y; out.eb[dst] = so.n_emit.z; }
-        out.id[dst] = so.id;
-        out.offset[dst] = so.offset;
-      }
+      if (so.keep) pt_q_store<EMIT>(out, dst, so.n_o, so.n_d, so.n_attn, so.n_emit, so.id, so.offset);
     } else {
       __syncthreads(); /* lds_win */
     }
@@ -2006,8 +2314,7 @@ __global__ void k_math_eval(int fn, long long n, const double* __restrict__ a, c
 __global__ void k_load_rays(long long n, const double* __restrict__ o, const double* __restrict__ d, PtQueue q) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  q.ox[i] = o[3 * i]; q.oy[i] = o[3 * i + 1]; q.oz[i] = o[3 * i + 2];
-  q.dx[i] = d[3 * i]; q.dy[i] = d[3 * i + 1]; q.dz[i] = d[3 * i + 2];
+  pt_q_store_ray(q, (uint32_t)i, v3(o[3 * i], o[3 * i + 1], o[3 * i + 2]), v3(d[3 * i], d[3 * i + 1], d[3 * i + 2]));
 }
 
 #include "bvh_build_gpu.inc"

@@ -337,7 +337,8 @@ def test_random_configs_raw_sums_bitwise(P, oracle, seed, monkeypatch):
          "cornell": lambda: oracle.desc_cornell(w, h), "ganesha": lambda: oracle.desc_ganesha_like(w, h, n_target=4000)}[kind]()
     monkeypatch.setenv("PTX_TRACE_STREAM", str(int(rng.integers(0, 2))))  # both trace kernels on every kind of scene
     monkeypatch.setenv("PTX_STREAMS", str(int(rng.integers(1, 5))))  # batches in flight
-    monkeypatch.setenv("PTX_SHADE_SPLIT", str(int(rng.integers(0, 2))))  # category-sorting shade kernel / per-category stage queues
+    monkeypatch.setenv("PTX_SHADE_SPLIT", str(int(rng.integers(0, 2))))  # per-category stage queues (wins over PTX_SHADE_POOL)
+    monkeypatch.setenv("PTX_SHADE_POOL", str(int(rng.integers(0, 2))))  # barrier-free pooled shade kernel / category-sorted windows
     monkeypatch.setenv("PTX_TRACE_BLOCK", str(int(rng.choice([0, 64, 256, 512, 1024]))))  # trace workgroup size (0 = by schedule)
     monkeypatch.setenv("PTX_TRACE_WGS", str(int(rng.integers(0, 4))))  # trace workgroups per CU (0 = as many as fit)
     monkeypatch.setenv("PTX_BIN_KEY", str(int(rng.integers(0, 2))))  # survivors binned by octant / by elevation
@@ -386,28 +387,34 @@ def test_tail_cut_and_threaded_walk_under_small_grids(P, oracle, kind, block, wg
 
 
 @pytest.mark.parametrize("kind", ["shirley", "cornell", "ganesha"])
-def test_per_category_stage_queues_equal_the_sorting_shade_kernel(P, oracle, kind, monkeypatch):
-    """PTX_SHADE_SPLIT=1 (k_classify + one k_shade_cat per material category) against the default k_shade and the
-    oracle: raw sums bit for bit, per-sample radiance bit for bit, with emitters (cornell) and triangles (ganesha)."""
+def test_the_three_shade_stage_implementations_agree(P, oracle, kind, monkeypatch):
+    """The default k_shade_pool (per-wave category pools, blocked output queue with holes), k_shade (category-sorted
+    windows, PTX_SHADE_POOL=0) and PTX_SHADE_SPLIT=1 (k_classify + one k_shade_cat per material category) against the
+    oracle: raw sums bit for bit, per-sample radiance bit for bit, the segment count (holes are not rays), with emitters
+    (cornell) and triangles (ganesha)."""
     torch = pytest.importorskip("torch")
     w, h, spp, depth = 160, 100, 5, 8
     d = {"shirley": lambda: oracle.desc_shirley(w, h), "cornell": lambda: oracle.desc_cornell(w, h),
          "ganesha": lambda: oracle.desc_ganesha_like(w, h, n_target=5000)}[kind]()
-    c = oracle.Scene(d.ptr, d).render(w, h, spp, depth, threads=8, want_raw=True)
+    c = oracle.Scene(d.ptr, d).render(w, h, spp, depth, threads=8, want_raw=True, count=True)
     raws = []
-    for split in ("0", "1"):
+    for split, pool in (("0", "1"), ("0", "0"), ("1", "1")):
         monkeypatch.setenv("PTX_SHADE_SPLIT", split)  # read when the scene handle is created
+        monkeypatch.setenv("PTX_SHADE_POOL", pool)
         g = P.Scene(d.ptr, 0, keepalive=d)
         raw = torch.zeros((h, w, 3), dtype=torch.float64, device="cuda:0")
-        g.render_raw_device(P.render_params(w, h, spp, depth, passes_per_batch=2), raw.data_ptr())
+        st = g.render_raw_device(P.render_params(w, h, spp, depth, passes_per_batch=2, count_work=True), raw.data_ptr())
+        for k in ("segments", "nodes_tested", "prims_tested"):
+            assert st[k] == c["counters"][k], (split, pool, k)
         raws.append(raw.cpu().numpy())
         rng = np.random.default_rng(4)
         xs, ys, ps = rng.integers(0, w, 4000), rng.integers(0, h, 4000), rng.integers(0, spp, 4000)
         g_rgb, _ = g.trace_samples(w, h, spp, depth, xs, ys, ps)
         o_rgb, _ = oracle.Scene(d.ptr, d).trace_samples(w, h, spp, depth, xs, ys, ps)
-        assert np.array_equal(bits(g_rgb), bits(o_rgb)), f"split={split}: per-sample radiance differs from the oracle"
+        assert np.array_equal(bits(g_rgb), bits(o_rgb)), f"split={split} pool={pool}: per-sample radiance differs from the oracle"
         g.close()
-    assert np.array_equal(bits(raws[0]), bits(c["raw"])) and np.array_equal(bits(raws[1]), bits(c["raw"]))
+    for r in raws:
+        assert np.array_equal(bits(r), bits(c["raw"]))
 
 
 @pytest.mark.parametrize("num_bins,cutoff", [(4, 4), (8, 8), (16, 2), (64, 12)])
