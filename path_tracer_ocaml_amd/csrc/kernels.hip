@@ -1399,7 +1399,8 @@ __device__ __forceinline__ PtSurface pt_surface_hit(const PtSceneDev& sc, V3 o, 
   /* tex_coord feeds Texture.eval only, and only a checker reads it */
   const bool need_uv = CAT == PT_CAT_LAMBERT_SOLID || CAT == PT_CAT_DIELECTRIC ? false
                        : (CAT == PT_CAT_LAMBERT_CHECKER ? true : ((m.kind != 2) && (m.tex_kind != 0)));
-  if (sc.slot_kind[slot] == PT_SLOT_SPHERE) {
+  /* (a scene without triangles: no load of the slot's kind in front of the loads of its geometry) */
+  if (!sc.has_triangles || sc.slot_kind[slot] == PT_SLOT_SPHERE) {
     /* Sphere.hit (sphere.ml:56-69) */
     const double* s = sc.sph + (size_t)slot * 4;
     const V3 center = v3(s[0], s[1], s[2]);
@@ -1532,11 +1533,12 @@ static_assert(PT_APPEND_BINS == 1 || PT_APPEND_BINS == 8, "the bin key has 8 val
  * bounce-1 rays, 512-entry windows: wave steps per ray 0.656 (octant) -> 0.584 (elevation); sorting by the true length would give
  * 0.485.  Measured: frame 36.96 -> 35.87 ms.  Other scenes (cornell's closed box, a mesh): the direction OCTANT (rays of a
  * wave share the child order), which measured 1.5-2 % better there. */
+template <int BINS = 8>
 __device__ __forceinline__ int pt_bin_key(const PtSceneDev& sc, V3 d) {
   if (sc.sort_by_elevation) {
     const float e = (float)d.x * (float)sc.sort_axis[0] + (float)d.y * (float)sc.sort_axis[1] + (float)d.z * (float)sc.sort_axis[2];
-    const int b = (int)((e + 1.0f) * 4.0f);
-    return b < 0 ? 0 : (b > 7 ? 7 : b);
+    const int b = (int)((e + 1.0f) * (0.5f * (float)BINS));
+    return b < 0 ? 0 : (b > BINS - 1 ? BINS - 1 : b);
   }
   return (d.x >= 0.0 ? 1 : 0) | (d.y >= 0.0 ? 2 : 0) | (d.z >= 0.0 ? 4 : 0);
 }
@@ -1626,7 +1628,8 @@ struct PtShadeOut {
 template <bool EMIT, bool PRIMARY, int CAT>
 __device__ __forceinline__ void pt_shade_entry(const PtSceneDev& sc, const PtQueue& q, const PtHits& hits, const PtContrib& contrib,
                                                const double* __restrict__ alpha, int bounce, int last_bounce,
-                                               const PtGenParams& g, uint32_t i, bool live, PtShadeOut& so) {
+                                               const PtGenParams& g, uint32_t i, bool live, PtShadeOut& so,
+                                               int known_slot = PT_SLOT_HOLE /* the entry's hit slot if the caller holds it */) {
     const double pi = 3.14159265358979323846;
     bool keep = false;
     V3 n_o = v3(0, 0, 0), n_d = v3(0, 0, 0), n_attn = v3(0, 0, 0), n_emit = v3(0, 0, 0);
@@ -1650,7 +1653,7 @@ __device__ __forceinline__ void pt_shade_entry(const PtSceneDev& sc, const PtQue
         pt_q_load_path(q, i, attn0, id, offset);
         if (EMIT) emit0 = pt_q_load_emit(q, i);
       }
-      const int slot = CAT == PT_CAT_MISS ? -1 : hits.slot[i];
+      const int slot = CAT == PT_CAT_MISS ? -1 : (known_slot != PT_SLOT_HOLE ? known_slot : hits.slot[i]);
       V3 result = v3(0, 0, 0);
       bool done = true;
       if (CAT == PT_CAT_MISS || (CAT == PT_CAT_NONE && slot < 0)) {
@@ -1658,7 +1661,7 @@ __device__ __forceinline__ void pt_shade_entry(const PtSceneDev& sc, const PtQue
         result = v3_fma(attn0, pt_background(sc, d), emit0);
       } else {
         const double t_hit = hits.t[i];
-        const bool is_tri = sc.slot_kind[slot] != PT_SLOT_SPHERE;
+        const bool is_tri = sc.has_triangles && sc.slot_kind[slot] != PT_SLOT_SPHERE;
         const PtSurface sf = pt_surface_hit<CAT>(sc, o, d, slot, t_hit, is_tri ? hits.u[i] : 0.0, is_tri ? hits.v[i] : 0.0);
         const PtShadeRec& m = *sf.m;
         const V3 point = sf.point;
@@ -1891,6 +1894,14 @@ __global__ __launch_bounds__(PT_SHADE_BLOCK, PT_SHADE_WAVES) void k_shade(PtScen
 #ifndef PT_POOL_BLOCK
 #define PT_POOL_BLOCK 256 /* < 4096 - 16 * 64: the cursor field must hold a full block plus one stray reservation per wave */
 #endif
+#ifndef PT_POOL_THREADS
+#define PT_POOL_THREADS 256 /* workgroup of k_shade_pool: nothing in it is workgroup-wide but the output blocks; 4 waves per
+                               workgroup interleave with a co-scheduled batch's trace workgroups at a finer grain than 8
+                               (two batches in flight: 27.6 ms against 29.6 ms on the headline frame; 128: 29.0 ms) */
+#endif
+#ifndef PT_POOL_BINS
+#define PT_POOL_BINS 8 /* output bins per workgroup (<= 64: one lane each in pt_pool_push); octant-keyed scenes use the first 8 */
+#endif
 #ifndef PT_POOL_RUN
 #define PT_POOL_RUN 32 /* a workgroup's share of the input: runs of this many consecutive chunks, dealt round-robin; its waves take
                           the chunks of a run one by one (LDS counter), so they shade neighbouring chunks at the same time and a block of
@@ -1905,12 +1916,12 @@ __global__ __launch_bounds__(PT_SHADE_BLOCK, PT_SHADE_WAVES) void k_shade(PtScen
 template <bool EMIT>
 __device__ __forceinline__ void pt_pool_push(const PtSceneDev& sc, const PtQueue& out, const PtShadeOut& so, uint32_t* lds_out) {
   const int lane = pt_lane();
-  const int bin = pt_bin_key(sc, so.n_d);
+  const int bin = pt_bin_key<PT_POOL_BINS>(sc, so.n_d);
   if (__ballot(so.keep) == 0) return;
   /* all bins at once: lane b < 8 holds bin b's survivor count and makes its reservation -- one LDS atomic instruction */
   uint32_t rank = 0, kk = 0;
 #pragma unroll
-  for (int b = 0; b < PT_APPEND_BINS; ++b) {
+  for (int b = 0; b < PT_POOL_BINS; ++b) {
     const unsigned long long m = __ballot(so.keep && bin == b);
     if (bin == b) rank = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
     if (lane == b) kk = (uint32_t)__popcll(m);
@@ -1963,11 +1974,11 @@ __device__ __forceinline__ void pt_pool_push(const PtSceneDev& sc, const PtQueue
 }
 
 template <bool EMIT, bool PRIMARY>
-__global__ __launch_bounds__(PT_SHADE_BLOCK, PT_SHADE_WAVES) void k_shade_pool(PtSceneDev sc, PtQueue q, PtHits hits, PtQueue out, PtContrib contrib,
+__global__ __launch_bounds__(PT_POOL_THREADS, PT_SHADE_WAVES) void k_shade_pool(PtSceneDev sc, PtQueue q, PtHits hits, PtQueue out, PtContrib contrib,
                                                 const double* __restrict__ alpha, int bounce, int last_bounce,
                                                 PtGenParams g, uint32_t n_primary, uint32_t* work) {
-  __shared__ uint32_t lds_pool[PT_SHADE_BLOCK / 64][PT_N_SHADE_CAT][128];
-  __shared__ uint32_t lds_out[PT_APPEND_BINS];
+  __shared__ uint2 lds_pool[PT_POOL_THREADS / 64][PT_N_SHADE_CAT][128]; /* (queue index, hit slot) */
+  __shared__ uint32_t lds_out[PT_POOL_BINS];
   __shared__ uint32_t lds_chunk_ctr, lds_done;
   const int lane = pt_lane(), wave = (int)(threadIdx.x >> 6), nw = (int)(blockDim.x >> 6);
   const uint32_t n = PRIMARY ? n_primary : *q.count;
@@ -1976,16 +1987,16 @@ __global__ __launch_bounds__(PT_SHADE_BLOCK, PT_SHADE_WAVES) void k_shade_pool(P
   n_wg = n_wg < 1u ? 1u : (n_wg > gridDim.x ? gridDim.x : n_wg);
   if (blockIdx.x >= n_wg) return; /* workgroup-uniform */
   if (threadIdx.x == 0) { lds_chunk_ctr = 0u; lds_done = 0u; }
-  if (threadIdx.x < PT_APPEND_BINS) lds_out[threadIdx.x] = (PT_POOL_NO_BLOCK << 12) | (uint32_t)PT_POOL_BLOCK; /* "full": the first push brings a block */
+  if (threadIdx.x < PT_POOL_BINS) lds_out[threadIdx.x] = (PT_POOL_NO_BLOCK << 12) | (uint32_t)PT_POOL_BLOCK; /* "full": the first push brings a block */
   __syncthreads(); /* the only workgroup barrier */
-  uint32_t (*pool)[128] = lds_pool[wave];
+  uint2 (*pool)[128] = lds_pool[wave];
   uint32_t cnt[PT_N_SHADE_CAT];
 #pragma unroll
   for (int k = 0; k < PT_N_SHADE_CAT; ++k) cnt[k] = 0u;
   /* raw chunks are classified through a two-stage pipeline, so that neither of the two dependent loads (hit slot, then the
    * slot's category) is waited for: stage B holds a chunk whose slots are on their way, stage C one whose categories are */
   uint32_t iB = 0u, iC = 0u;
-  int slotB = PT_SLOT_HOLE, catC = PT_CAT_NONE;
+  int slotB = PT_SLOT_HOLE, slotC = PT_SLOT_HOLE, catC = PT_CAT_NONE;
   bool haveB = false, haveC = false; /* wave-uniform */
 #define PT_POOL_TAKE_B() do { \
     uint32_t unit_ = 0u; \
@@ -2002,7 +2013,7 @@ __global__ __launch_bounds__(PT_SHADE_BLOCK, PT_SHADE_WAVES) void k_shade_pool(P
     } \
   } while (0)
 #define PT_POOL_ADVANCE() do { \
-    iC = iB; haveC = haveB; \
+    iC = iB; haveC = haveB; slotC = slotB; \
     catC = slotB == PT_SLOT_HOLE ? PT_CAT_NONE : (slotB < 0 ? PT_CAT_MISS : (int)sc.slot_cat[slotB]); \
     PT_POOL_TAKE_B(); \
   } while (0)
@@ -2030,18 +2041,23 @@ __global__ __launch_bounds__(PT_SHADE_BLOCK, PT_SHADE_WAVES) void k_shade_pool(P
       const bool live = (uint32_t)lane < take;
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); /* this wave's own pushes below */
       uint32_t i = 0u;
+      int sl = -1;
       PtShadeOut so;
       so.keep = false;
 #pragma unroll
       for (int k = 0; k < PT_N_SHADE_CAT; ++k) {
         if (c == k) { /* wave-uniform */
           cnt[k] = start;
-          if (live) i = pool[k][start + lane];
+          if (live) {
+            const uint2 e = pool[k][start + lane];
+            i = e.x;
+            sl = (int)e.y;
+          }
           if (k == PT_CAT_MISS) pt_shade_entry<EMIT, PRIMARY, PT_CAT_MISS>(sc, q, hits, contrib, alpha, bounce, last_bounce, g, i, live, so);
-          if (k == PT_CAT_LAMBERT_SOLID) pt_shade_entry<EMIT, PRIMARY, PT_CAT_LAMBERT_SOLID>(sc, q, hits, contrib, alpha, bounce, last_bounce, g, i, live, so);
-          if (k == PT_CAT_LAMBERT_CHECKER) pt_shade_entry<EMIT, PRIMARY, PT_CAT_LAMBERT_CHECKER>(sc, q, hits, contrib, alpha, bounce, last_bounce, g, i, live, so);
-          if (k == PT_CAT_METAL) pt_shade_entry<EMIT, PRIMARY, PT_CAT_METAL>(sc, q, hits, contrib, alpha, bounce, last_bounce, g, i, live, so);
-          if (k == PT_CAT_DIELECTRIC) pt_shade_entry<EMIT, PRIMARY, PT_CAT_DIELECTRIC>(sc, q, hits, contrib, alpha, bounce, last_bounce, g, i, live, so);
+          if (k == PT_CAT_LAMBERT_SOLID) pt_shade_entry<EMIT, PRIMARY, PT_CAT_LAMBERT_SOLID>(sc, q, hits, contrib, alpha, bounce, last_bounce, g, i, live, so, sl);
+          if (k == PT_CAT_LAMBERT_CHECKER) pt_shade_entry<EMIT, PRIMARY, PT_CAT_LAMBERT_CHECKER>(sc, q, hits, contrib, alpha, bounce, last_bounce, g, i, live, so, sl);
+          if (k == PT_CAT_METAL) pt_shade_entry<EMIT, PRIMARY, PT_CAT_METAL>(sc, q, hits, contrib, alpha, bounce, last_bounce, g, i, live, so, sl);
+          if (k == PT_CAT_DIELECTRIC) pt_shade_entry<EMIT, PRIMARY, PT_CAT_DIELECTRIC>(sc, q, hits, contrib, alpha, bounce, last_bounce, g, i, live, so, sl);
         }
       }
       PT_TM(tm_entry, tm_t);
@@ -2057,7 +2073,7 @@ __global__ __launch_bounds__(PT_SHADE_BLOCK, PT_SHADE_WAVES) void k_shade_pool(P
 #pragma unroll
     for (int k = 0; k < PT_N_SHADE_CAT; ++k) {
       const unsigned long long m = __ballot(catC == k);
-      if (catC == k) pool[k][cnt[k] + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = iC;
+      if (catC == k) pool[k][cnt[k] + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = make_uint2(iC, (uint32_t)slotC);
       cnt[k] += (uint32_t)__popcll(m);
     }
     PT_POOL_ADVANCE();
@@ -2088,7 +2104,7 @@ __global__ __launch_bounds__(PT_SHADE_BLOCK, PT_SHADE_WAVES) void k_shade_pool(P
   if (lane == 0) done = __hip_atomic_fetch_add(&lds_done, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
   done = (uint32_t)__builtin_amdgcn_readfirstlane((int)done);
   if (done != (uint32_t)(nw - 1)) return;
-  for (int b = 0; b < PT_APPEND_BINS; ++b) {
+  for (int b = 0; b < PT_POOL_BINS; ++b) {
     const uint32_t st = __hip_atomic_load(lds_out + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     const uint32_t blk = st >> 12, pos = st & 0xfffu;
     if (blk == PT_POOL_NO_BLOCK) continue;
