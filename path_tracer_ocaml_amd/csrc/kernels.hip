@@ -1534,11 +1534,22 @@ static_assert(PT_APPEND_BINS == 1 || PT_APPEND_BINS == 8, "the bin key has 8 val
  * 0.485.  Measured: frame 36.96 -> 35.87 ms.  Other scenes (cornell's closed box, a mesh): the direction OCTANT (rays of a
  * wave share the child order), which measured 1.5-2 % better there. */
 template <int BINS = 8>
-__device__ __forceinline__ int pt_bin_key(const PtSceneDev& sc, V3 d) {
+__device__ __forceinline__ int pt_bin_key(const PtSceneDev& sc, V3 o, V3 d) {
   if (sc.sort_by_elevation) {
     const float e = (float)d.x * (float)sc.sort_axis[0] + (float)d.y * (float)sc.sort_axis[1] + (float)d.z * (float)sc.sort_axis[2];
     const int b = (int)((e + 1.0f) * (0.5f * (float)BINS));
     return b < 0 ? 0 : (b > BINS - 1 ? BINS - 1 : b);
+  }
+  if (sc.sort_by_root) {
+    const float ox = (float)o.x, oy = (float)o.y, oz = (float)o.z;
+    const float ix = 1.0f / (float)d.x, iy = 1.0f / (float)d.y, iz = 1.0f / (float)d.z;
+    const float ax = (sc.root_mn[0] - ox) * ix, bx = (sc.root_mx[0] - ox) * ix;
+    const float ay = (sc.root_mn[1] - oy) * iy, by = (sc.root_mx[1] - oy) * iy;
+    const float az = (sc.root_mn[2] - oz) * iz, bz = (sc.root_mx[2] - oz) * iz;
+    const float t_in = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), 0.0f));
+    const float t_out = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
+    const bool reaches = !(t_out < t_in); /* a NaN (0 * inf) counts as reaching */
+    return (reaches ? 4 : 0) | (d.x >= 0.0 ? 1 : 0) | (d.z >= 0.0 ? 2 : 0);
   }
   return (d.x >= 0.0 ? 1 : 0) | (d.y >= 0.0 ? 2 : 0) | (d.z >= 0.0 ? 4 : 0);
 }
@@ -1828,7 +1839,7 @@ __global__ __launch_bounds__(PT_SHADE_BLOCK, PT_SHADE_WAVES) void k_shade(PtScen
     const uint32_t id = so.id;
     const int offset = so.offset;
 #if PT_APPEND_BINS > 1
-    const int octant = pt_bin_key(sc, n_d);
+    const int octant = pt_bin_key(sc, n_o, n_d);
     /* with the category sort on, its three barriers separate one append from the next */
 #if PT_SHADE_TIMING
     const uint32_t dst = pt_block_append_binned<!(PT_SHADE_SORT && !PRIMARY)>(out.count, keep, octant, lds_bins, &tm_wait);
@@ -1895,9 +1906,11 @@ __global__ __launch_bounds__(PT_SHADE_BLOCK, PT_SHADE_WAVES) void k_shade(PtScen
 #define PT_POOL_BLOCK 256 /* < 4096 - 16 * 64: the cursor field must hold a full block plus one stray reservation per wave */
 #endif
 #ifndef PT_POOL_THREADS
-#define PT_POOL_THREADS 256 /* workgroup of k_shade_pool: nothing in it is workgroup-wide but the output blocks; 4 waves per
-                               workgroup interleave with a co-scheduled batch's trace workgroups at a finer grain than 8
-                               (two batches in flight: 27.6 ms against 29.6 ms on the headline frame; 128: 29.0 ms) */
+#define PT_POOL_THREADS 512 /* largest workgroup of k_shade_pool (the pools live in dynamic LDS, sized by blockDim).  Nothing in it is
+                               workgroup-wide but the output blocks: when two batches share every CU it runs 256-thread workgroups,
+                               which interleave with the other batch's trace workgroups at a finer grain (headline frame 27.6 ms
+                               against 29.6 ms with 512, 29.0 ms with 128); alone on the chip 512 is 2-6 % faster (fewer
+                               part-filled blocks, larger shares) */
 #endif
 #ifndef PT_POOL_BINS
 #define PT_POOL_BINS 8 /* output bins per workgroup (<= 64: one lane each in pt_pool_push); octant-keyed scenes use the first 8 */
@@ -1916,7 +1929,7 @@ __global__ __launch_bounds__(PT_SHADE_BLOCK, PT_SHADE_WAVES) void k_shade(PtScen
 template <bool EMIT>
 __device__ __forceinline__ void pt_pool_push(const PtSceneDev& sc, const PtQueue& out, const PtShadeOut& so, uint32_t* lds_out) {
   const int lane = pt_lane();
-  const int bin = pt_bin_key<PT_POOL_BINS>(sc, so.n_d);
+  const int bin = pt_bin_key<PT_POOL_BINS>(sc, so.n_o, so.n_d);
   if (__ballot(so.keep) == 0) return;
   /* all bins at once: lane b < 8 holds bin b's survivor count and makes its reservation -- one LDS atomic instruction */
   uint32_t rank = 0, kk = 0;
@@ -1977,7 +1990,7 @@ template <bool EMIT, bool PRIMARY>
 __global__ __launch_bounds__(PT_POOL_THREADS, PT_SHADE_WAVES) void k_shade_pool(PtSceneDev sc, PtQueue q, PtHits hits, PtQueue out, PtContrib contrib,
                                                 const double* __restrict__ alpha, int bounce, int last_bounce,
                                                 PtGenParams g, uint32_t n_primary, uint32_t* work) {
-  __shared__ uint2 lds_pool[PT_POOL_THREADS / 64][PT_N_SHADE_CAT][128]; /* (queue index, hit slot) */
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_pool_raw[]; /* [waves][PT_N_SHADE_CAT][128] x (queue index, hit slot) */
   __shared__ uint32_t lds_out[PT_POOL_BINS];
   __shared__ uint32_t lds_chunk_ctr, lds_done;
   const int lane = pt_lane(), wave = (int)(threadIdx.x >> 6), nw = (int)(blockDim.x >> 6);
@@ -1989,7 +2002,7 @@ __global__ __launch_bounds__(PT_POOL_THREADS, PT_SHADE_WAVES) void k_shade_pool(
   if (threadIdx.x == 0) { lds_chunk_ctr = 0u; lds_done = 0u; }
   if (threadIdx.x < PT_POOL_BINS) lds_out[threadIdx.x] = (PT_POOL_NO_BLOCK << 12) | (uint32_t)PT_POOL_BLOCK; /* "full": the first push brings a block */
   __syncthreads(); /* the only workgroup barrier */
-  uint2 (*pool)[128] = lds_pool[wave];
+  uint2 (*pool)[128] = (uint2 (*)[128])lds_pool_raw + (size_t)wave * PT_N_SHADE_CAT;
   uint32_t cnt[PT_N_SHADE_CAT];
 #pragma unroll
   for (int k = 0; k < PT_N_SHADE_CAT; ++k) cnt[k] = 0u;
@@ -2224,7 +2237,7 @@ __global__ __launch_bounds__(PT_SHADE_BLOCK, PT_SHADE_CAT_WAVES) void k_shade_ca
     PtShadeOut so;
     pt_shade_entry<EMIT, PRIMARY, CAT>(sc, q, hits, contrib, alpha, bounce, last_bounce, g, i, live, so);
     if (CAT != PT_CAT_MISS) {
-      const int octant = pt_bin_key(sc, so.n_d);
+      const int octant = pt_bin_key(sc, so.n_o, so.n_d);
       const uint32_t dst = pt_block_append_binned<true>(out.count, so.keep, octant, lds_bins);
       if (so.keep) pt_q_store<EMIT>(out, dst, so.n_o, so.n_d, so.n_attn, so.n_emit, so.id, so.offset);
     } else {

@@ -110,7 +110,11 @@ struct PtSceneDev {
    * predictor of how long the next walk is); it never enters a pixel value. */
   double sort_axis[3];
   int32_t sort_by_elevation; /* 1: the centres do lie in a slab (smallest variance < 2 % of the largest): bin by elevation; 0: by direction octant */
-  int32_t pad1;
+  /* 1: bin by whether the new ray reaches the tree's bounding box at all (+ two direction signs).  Scenes whose rays mostly start
+   * OUTSIDE the tree (a mesh standing on a floor that is tested before the tree): a ray that misses the box costs one node test, one
+   * that enters it walks a hundred nodes, and a wave that holds both waits for the longest.  Heuristic, binary32, never enters a pixel. */
+  int32_t sort_by_root;
+  float root_mn[3], root_mx[3];
   double cam_llx, cam_lly, cam_vx, cam_vy;
   int32_t bg_kind;
   int32_t pad0;
