@@ -341,6 +341,7 @@ def test_random_configs_raw_sums_bitwise(P, oracle, seed, monkeypatch):
     monkeypatch.setenv("PTX_SHADE_POOL", str(int(rng.integers(0, 2))))  # barrier-free pooled shade kernel / category-sorted windows
     monkeypatch.setenv("PTX_TRACE_BLOCK", str(int(rng.choice([0, 64, 256, 512, 1024]))))  # trace workgroup size (0 = by schedule)
     monkeypatch.setenv("PTX_TRACE_WGS", str(int(rng.integers(0, 4))))  # trace workgroups per CU (0 = as many as fit)
+    monkeypatch.setenv("PTX_SHADE_WGS", str(int(rng.integers(0, 4))))  # pooled shade workgroups per CU (0 = by schedule)
     monkeypatch.setenv("PTX_BIN_KEY", str(int(rng.integers(0, 3))))  # survivors binned by octant / elevation / reaches-the-tree's-box
     o_scene = oracle.Scene(d.ptr, d)
     g_scene = P.Scene(d.ptr, 0, keepalive=d)
