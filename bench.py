@@ -326,6 +326,19 @@ def main():
                          "timing": "HIP events on the launch stream, one-stream pass (PTX_STREAMS=1)",
                          "pipeline": {"bytes_per_sample": b_total / samples, "achieved": b_total * args.steps / elapsed * 1e-9,
                                       "unit": "GB/s (algorithmic, SURVEY section 8 D)"}})
+        # second kernel: the shade stage moves the bytes.  Algorithmic HBM bytes of one step: every
+        # segment reads its queue entry (ray 48 B + path state 32 B [+ carried emission 32 B]) and its hit record (12 B);
+        # a segment that survives writes the next entry (80 B [+ 32 B]), a path that ends writes one 32-byte contribution.
+        # survivors = segments - samples (every segment after a path's first was written by a survivor).
+        emit_b = 32 if scene_name == "cornell" else 0
+        segs = counts["segments"]
+        shade_bytes = segs * (80 + emit_b + 12) + max(segs - counts["samples"], 0) * (80 + emit_b) + counts["samples"] * 32
+        shade_s = kernel_ms["shade"] * 1e-3  # rank 0's share; the ranks run side by side, so job bytes / this = aggregate rate
+        shade_gbs = shade_bytes / shade_s * 1e-9 if shade_s > 0 else None
+        roofline["shade"] = {"bound": "hbm", "kernel": "k_shade_pool", "achieved": shade_gbs, "peak": HBM_PEAK_GBS * world, "unit": "GB/s",
+                             "frac": (shade_gbs / (HBM_PEAK_GBS * world)) if shade_gbs else None,
+                             "algorithmic_bytes_per_step": shade_bytes, "ms_per_step_one_stream": kernel_ms["shade"],
+                             "timing": "HIP events on the launch stream, one-stream pass (PTX_STREAMS=1)"}
         # the host-framebuffer entry point the CLI and the OCaml stub call (one 24 B/pixel device-to-host copy more)
         try:
             scene.render(w, h, spp, depth)
