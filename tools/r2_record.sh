@@ -1,0 +1,11 @@
+#!/bin/bash
+# the short end-of-round record: full GPU suite log, smoke, the driver's bench command -> gpurun_out/r02_*
+mkdir -p gpurun_out
+python -m pytest tests -m gpu -x -q > gpurun_out/r02_pytest_gpu.log 2>&1; echo "pytest exit $?"; tail -2 gpurun_out/r02_pytest_gpu.log
+python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
+python bench.py > gpurun_out/r02_bench_n1.json 2> gpurun_out/r02_bench_n1.err; echo "bench exit $?"
+python - <<'PY'
+import json
+d=json.loads(open('gpurun_out/r02_bench_n1.json').read().strip().splitlines()[-1])
+print('headline', round(d['value'],1), 'Msamples/s', round(d['ms_per_step'],2), 'ms; roofline', d['roofline']['bound'], round(d['roofline']['frac'],3), 'shade', round(d['roofline']['shade']['frac'],3), 'cpu', d['cpu_baseline']['value'], 'parity', d['parity']['rel_linf_vs_cpu_ref'])
+PY
