@@ -339,6 +339,16 @@ def main():
                              "frac": (shade_gbs / (HBM_PEAK_GBS * world)) if shade_gbs else None,
                              "algorithmic_bytes_per_step": shade_bytes, "ms_per_step_one_stream": kernel_ms["shade"],
                              "timing": "HIP events on the launch stream, one-stream pass (PTX_STREAMS=1)"}
+        # how much of the step the vector pipe is busy: sum over stages of (one-stream kernel time x the stage's tracked
+        # SQ_ACTIVE_INST_VALU share) against the step as timed.  Trace and shade of two batches run side by side on every
+        # CU, so this -- not either kernel's own roofline -- is what the frame converges to.
+        vb_t, vb_s = tc.get("valu_busy_trace_time_weighted"), tc.get("valu_busy_shade_time_weighted")
+        if vb_t is not None and vb_s is not None:
+            valu_ms = kernel_ms["trace"] * vb_t + kernel_ms["shade"] * vb_s
+            roofline["frame"] = {"bound": "valu_issue", "valu_busy_ms_per_step": valu_ms, "ms_per_step": ms_per_step,
+                                 "frac": valu_ms / ms_per_step if ms_per_step > 0 else None,
+                                 "valu_busy_share": {"trace": vb_t, "shade": vb_s}, "source": tc.get("source"),
+                                 "note": "vector-pipe busy time of the step's kernels (one-stream durations x tracked counter shares) / the step"}
         # the host-framebuffer entry point the CLI and the OCaml stub call (one 24 B/pixel device-to-host copy more)
         try:
             scene.render(w, h, spp, depth)

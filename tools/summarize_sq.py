@@ -134,6 +134,14 @@ if tr:
     for key in ("valu_busy", "lane_util", "useful_issue_frac", "lds_busy", "lds_bank_conflict_share", "wait_any", "wait_inst_any", "wave_residency"):
         entry[key] = dom.get(key)
     entry["counters_of"] = [k for k, e in out["kernels"].items() if e is dom][0]
+    # time-weighted share of SIMD time the vector pipe issues, per stage (timed instantiations only): what bench.py turns
+    # into the frame's vector-issue time (sum over stages of one-stream kernel time x this share)
+    for stage, pref in (("trace", ("k_trace<", "k_trace_stream<")), ("shade", ("k_shade<", "k_shade_pool<", "k_shade_cat<"))):
+        ks = [e for k, e in out["kernels"].items() if k.startswith(pref) and "one_stream" in e and e.get("valu_busy") is not None
+              and (stage != "trace" or is_timed_trace(k))]
+        tot = sum(e["one_stream"]["total_ms"] for e in ks)
+        if tot > 0:
+            entry[f"valu_busy_{stage}_time_weighted"] = sum(e["valu_busy"] * e["one_stream"]["total_ms"] for e in ks) / tot
     ri[workload] = entry
     json.dump(ri, open(ri_path, "w"), indent=1)
     print(json.dumps(entry, indent=1))
