@@ -433,3 +433,38 @@ def test_gpu_bvh_build_other_bin_counts_and_cutoffs(P, oracle, num_bins, cutoff)
     gb, gi, go = g.tree()
     assert np.array_equal(bits(gb), bits(ob)) and np.array_equal(gi, oi) and np.array_equal(go, oo)
     g.close()
+
+
+@pytest.mark.parametrize("pool", ["1", "0"])
+def test_state_after_the_first_scatter(P, oracle, pool, monkeypatch):
+    """ptx_debug_first_scatter reads the queue the first shade launch leaves behind -- with the pooled shade kernel a blocked
+    queue whose part-filled blocks end in holes: every surviving path's next ray and attenuation must be the oracle's bit for bit,
+    the same paths must be alive, and no hole may be taken for a path."""
+    import ctypes as C
+    from path_tracer_ocaml_amd import abi
+    monkeypatch.setenv("PTX_SHADE_POOL", pool)
+    w, h, spp, depth = 200, 120, 8, 6
+    d = oracle.desc_shirley(w, h)
+    o = oracle.Scene(d.ptr, d)
+    g = P.Scene(d.ptr, 0, keepalive=d)
+    rng = np.random.default_rng(11)
+    n = 30000
+    xs, ys, ps = [np.ascontiguousarray(a, dtype=np.int32) for a in (rng.integers(0, w, n), rng.integers(0, h, n), rng.integers(0, spp, n))]
+    ip, dp = oracle.ip, oracle.dp
+    c_ray, c_att, c_alive, info = np.zeros((n, 6)), np.zeros((n, 3)), np.zeros(n, dtype=np.int32), np.zeros((n, 3), dtype=np.int32)
+    L = oracle.lib()
+    L.orc_debug_first_scatter.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int64, ip, ip, ip, dp, dp, ip, ip]
+    L.orc_debug_first_scatter(o._h, w, h, spp, depth, n, xs.ctypes.data_as(ip), ys.ctypes.data_as(ip), ps.ctypes.data_as(ip),
+                              c_ray.ctypes.data_as(dp), c_att.ctypes.data_as(dp), c_alive.ctypes.data_as(ip), info.ctypes.data_as(ip))
+    g_ray, g_att, g_alive = np.zeros((n, 6)), np.zeros((n, 3)), np.zeros(n, dtype=np.int32)
+    G = P.lib()
+    G.ptx_debug_first_scatter.argtypes = [C.c_void_p, C.POINTER(abi.RenderParams), C.c_int64, ip, ip, ip, dp, dp, ip]
+    params = P.render_params(w, h, spp, depth)
+    rc = G.ptx_debug_first_scatter(g._h, C.byref(params), n, xs.ctypes.data_as(ip), ys.ctypes.data_as(ip), ps.ctypes.data_as(ip),
+                                   g_ray.ctypes.data_as(dp), g_att.ctypes.data_as(dp), g_alive.ctypes.data_as(ip))
+    assert rc == 0, P.last_error()
+    assert np.array_equal(c_alive, g_alive)
+    live = c_alive == 1
+    assert 0 < int(live.sum()) < n
+    assert np.array_equal(bits(g_ray[live]), bits(c_ray[live])) and np.array_equal(bits(g_att[live]), bits(c_att[live]))
+    g.close()
