@@ -2343,7 +2343,9 @@ __global__ void k_math_eval(int fn, long long n, const double* __restrict__ a, c
 __global__ void k_load_rays(long long n, const double* __restrict__ o, const double* __restrict__ d, PtQueue q) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  pt_q_store_ray(q, (uint32_t)i, v3(o[3 * i], o[3 * i + 1], o[3 * i + 2]), v3(d[3 * i], d[3 * i + 1], d[3 * i + 2]));
+  double dx = d[3 * i];
+  if (pt_is_hole(dx)) dx = __hiloint2double(0x7ff80000, 0); /* a caller's NaN that happens to carry the hole payload: any NaN walks alike */
+  pt_q_store_ray(q, (uint32_t)i, v3(o[3 * i], o[3 * i + 1], o[3 * i + 2]), v3(dx, d[3 * i + 1], d[3 * i + 2]));
 }
 
 #include "bvh_build_gpu.inc"

@@ -121,6 +121,25 @@ def test_intersect_rays_ganesha_like_with_floor(P, oracle):
     _check_intersect(oracle, P, oracle.desc_ganesha_like(192, 108, n_target=20000), n=20_000)
 
 
+def test_intersect_rays_nan_directions_including_the_hole_payload(P, oracle):
+    """A caller's ray whose direction x is a NaN -- the canonical one, a negative one, and one that happens to carry the payload
+    the blocked queues use to mark their holes -- walks like any NaN ray (every comparison false): a miss, counted as a segment
+    with the oracle's node tests, never mistaken for a hole."""
+    d = oracle.desc_shirley(160, 90)
+    o_scene = oracle.Scene(d.ptr, d)
+    g_scene = P.Scene(d.ptr, 0, keepalive=d)
+    org, dirs = _camera_rays(oracle, d, 512, 5)
+    payloads = [0x7ff8000000000000, 0xfff8000000000000, 0x7ff8dead00000000, 0x7ff8dead12345678]
+    for k, pl in enumerate(payloads):
+        dirs[k::37, 0] = np.array([pl], dtype=np.uint64).view(np.float64)[0]
+    t_c, p_c, ct_c = o_scene.intersect_rays(org, dirs)
+    t_g, p_g, st = g_scene.intersect_rays(org, dirs)
+    assert np.array_equal(p_g, p_c) and np.array_equal(bits(t_g), bits(t_c))
+    for key in ("segments", "nodes_tested", "prims_tested"):
+        assert st[key] == ct_c[key], key
+    g_scene.close()
+
+
 # ---------------------------------------------------------------- per-sample radiance: bit-exact
 def _check_samples(oracle, P, d, w, h, spp, depth, n=20_000, seed=3):
     o_scene = oracle.Scene(d.ptr, d)
