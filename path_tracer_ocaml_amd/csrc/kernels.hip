@@ -68,6 +68,9 @@ __device__ __forceinline__ V3 pt_q_load_emit(const PtQueue& q, uint32_t i) {
   return v3(a.x, a.y, b.x);
 }
 __device__ __forceinline__ void pt_q_store_ray(const PtQueue& q, uint32_t i, V3 o, V3 d) {
+  /* a real ray's NaN that happens to carry the hole payload (it can only come in through the caller's data: arithmetic
+   * produces the canonical NaN or hands an operand's payload on) is stored as the canonical NaN: any NaN walks alike */
+  if (pt_is_hole(d.x)) d.x = __hiloint2double(0x7ff80000, 0);
   double2* r = (double2*)(q.ray + i);
   r[0] = make_double2(o.x, o.y);
   r[1] = make_double2(o.z, d.x);
@@ -2343,9 +2346,7 @@ __global__ void k_math_eval(int fn, long long n, const double* __restrict__ a, c
 __global__ void k_load_rays(long long n, const double* __restrict__ o, const double* __restrict__ d, PtQueue q) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  double dx = d[3 * i];
-  if (pt_is_hole(dx)) dx = __hiloint2double(0x7ff80000, 0); /* a caller's NaN that happens to carry the hole payload: any NaN walks alike */
-  pt_q_store_ray(q, (uint32_t)i, v3(o[3 * i], o[3 * i + 1], o[3 * i + 2]), v3(dx, d[3 * i + 1], d[3 * i + 2]));
+  pt_q_store_ray(q, (uint32_t)i, v3(o[3 * i], o[3 * i + 1], o[3 * i + 2]), v3(d[3 * i], d[3 * i + 1], d[3 * i + 2]));
 }
 
 #include "bvh_build_gpu.inc"
