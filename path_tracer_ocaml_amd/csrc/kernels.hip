@@ -1,7 +1,9 @@
 /* kernels.hip -- the wavefront path integrator for gfx950 (MI355X), binary64 throughout.
  *
- * Stages (one kernel each, connected by SoA path queues that stay resident in HBM):
- *   generate : sampler dims 0,1 + Camera.ray            (integrator.ml:96-105, camera.ml:93-102)
+ * Stages (one kernel each, connected by path queues -- a 48-byte ray record + a 32-byte path-state record per entry -- that stay
+ * resident in HBM):
+ *   generate : sampler dims 0,1 + Camera.ray            (integrator.ml:96-105, camera.ml:93-102); fused into the bounce-0
+ *              launches of trace and shade (PRIMARY), a kernel of its own only for explicit sample lists
  *   trace    : Scene.intersect = ordered BVH walk + leaf packets (shape_tree.ml:198-220, lib.rs:102-178,
  *              sphere.ml:35-54, triangle.ml:74-98, ganesha floor pre-test main.ml:286-298)
  *   shade    : Sphere.hit / Triangle.Hit.to_hit, Material.scatter, the body of Integrator's path loop
@@ -21,7 +23,7 @@
 
 #define PT_WAVE 64
 
-/* ------------------------------------------------------------------ path queue (SoA in HBM) */
+/* ------------------------------------------------------------------ path queue (records in HBM) */
 /* A queue entry is two records: the ray (what k_trace reads, densely) and the rest of the path's state (what only the shade
  * stage reads, entry by entry in the order its category pools dictate -- one 32-byte sector instead of five 8-byte fields in
  * five different sectors).  Both are multiples of 16 bytes: every access is a 16-byte load or store. */
@@ -2136,7 +2138,7 @@ __global__ __launch_bounds__(PT_POOL_THREADS, PT_SHADE_WAVES) void k_shade_pool(
  * ~150 instructions, a checker Lambertian ~1200) between the same workgroup barriers: the short waves sat parked at the
  * barrier (SQ_WAIT_ANY 72 % of a wave's life, profiles/r02a_sq.json) and the register file was sized for the sum of
  * all five paths.  Per-category kernels keep every wave of a workgroup on the same path, need no sort, and are
- * register-allocated for one material each.  A list keeps queue order, so reads of the SoA queues stay clustered. */
+ * register-allocated for one material each.  A list keeps queue order, so reads of the queues stay clustered. */
 struct PtCatLists {
   uint32_t* idx;      /* PT_N_SHADE_CAT lists of `cap` entries each: queue (or virtual primary) indices */
   uint32_t* count;    /* PT_N_SHADE_CAT list lengths (device, zero at launch) */
