@@ -4,6 +4,8 @@ Bars: bit-exact for everything integer or per-sample (hit indices, work counters
 raw per-pixel sums); <= 1e-5 relative L-inf for the filtered post-gamma
 framebuffer, where only the f64 summation order differs.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -343,7 +345,7 @@ def test_gpu_bvh_build_equals_oracle_tree(P, oracle, name):
 
 
 # ---------------------------------------------------------------- seeded sweep over render configurations
-@pytest.mark.parametrize("seed", range(12))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("PTX_TEST_SEEDS", "12"))))  # a soak run sets a few hundred
 def test_random_configs_raw_sums_bitwise(P, oracle, seed, monkeypatch):
     """Random (scene, size, spp, depth, batching, band sharding, trace-kernel choice): the raw per-pixel sums are the
     oracle's bit for bit whatever way the work is cut up."""
