@@ -166,6 +166,58 @@ def real_reference(workload):
         return {"value": None, "why": f"{type(e).__name__}: {e}"}
 
 
+def launch_ranks(n, argv):
+    """One process per GPU, exactly as the driver launches them: `python -m torch.distributed.run --nnodes=1
+    --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py <argv>`, as a child of this process.  The
+    parent imports neither torch nor the library, so no GPU state exists here; it relays the child's output (rank 0
+    prints the one JSON line) and returns its exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    return subprocess.run(cmd, env=env).returncode
+
+
+def rehearse_launch(args, rank, world):
+    """The multi-rank plumbing of a step without a renderer (there is no CPU renderer in the product): every rank fills
+    its bands with a pattern that names (rank, local row), the ranks exchange them through BandGather over gloo, rank 0
+    checks every image row arrived where the film's row map expects it.  `value` is null: nothing was measured."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from path_tracer_ocaml_amd import distributed as D
+    _, w, h, _, _ = WORKLOADS[args.workload]
+    if world > 1:
+        dist.init_process_group("gloo")
+    bg = D.BandGather(h, w, rank, world, torch.device("cpu"))
+    rows = D.band_layout(h, world)[rank]
+    ok = True
+    for step in range(args.warmup + args.steps):
+        bg.part[:len(rows)] = torch.from_numpy(rows.astype(np.float64) + 0.25 * step)[:, None, None]
+        got = bg.gather()
+        if rank == 0:
+            img = D.ungather(got.numpy(), h, world)
+            ok = ok and bool((img[:, 0, 0] == np.arange(h) + 0.25 * step).all())
+    if rank == 0:
+        print(json.dumps({"metric": "Msamples/s (WxHxspp) + achieved HBM GB/s vs roofline; per-pixel Linf vs CPU ref", "value": None,
+                          "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": None,
+                          "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
+                          "data": "none (launch rehearsal over gloo: no GPU used, nothing rendered, nothing measured)",
+                          "config": {"workload": args.workload, "sharding": f"{world} rank(s), interleaved {D.BAND_ROWS}-row bands, 1 gather/step"},
+                          "rehearsal": {"bands_arrived_in_place": ok}}))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if not ok:
+        raise SystemExit("band exchange rehearsal failed")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -177,7 +229,15 @@ def main():
     ap.add_argument("--passes-per-batch", type=int, default=0)
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo = rehearsal of the multi-rank path on fewer GPUs than ranks (ranks share devices)")
+    ap.add_argument("--rehearse-launch", action="store_true",
+                    help="no GPU needed and nothing rendered: start the ranks, run the band exchange on synthetic bands over gloo "
+                         "and print a line with value null -- checks that `bench.py --gpus N` can start its own ranks")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: start the N ranks ourselves, as fresh child processes, before anything in
+        # this process has touched the GPU (it never does), and pass rank 0's JSON line and the exit code through
+        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))
 
     import torch
     import torch.distributed as dist
@@ -190,6 +250,8 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    if args.rehearse_launch:
+        return rehearse_launch(args, rank, world)
     if not torch.cuda.is_available():
         raise SystemExit("no GPU visible: this benchmark has no CPU fallback")
     n_dev = torch.cuda.device_count()

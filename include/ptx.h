@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define PTX_ABI_VERSION 2
+#define PTX_ABI_VERSION 3
 
 /* ---- materials: Material.t, path_tracer/src/material.ml:3-14 ---- */
 #define PTX_MAT_LAMBERTIAN 0 /* Lambertian of Texture.t */
@@ -169,6 +169,16 @@ typedef struct ptx_stats {
   double build_ms; /* BVH build + upload at ptx_scene_create */
   int32_t traversal_in_lds; /* 1: tree + leaf packets fit the per-workgroup LDS copy; 0: traversed from HBM / L2 */
   int32_t bvh_built_on_gpu; /* 1: csrc/bvh_build_gpu.inc built the tree, 0: the host builder (same tree) */
+  /* if count_work: Bbox.is_hit evaluations the binary32 filter in front of the binary64 slab test could NOT decide (they
+   * then ran the reference's binary64 arithmetic, bbox.ml:40-56), and the wave steps that entered that branch.  Both
+   * are 0 for walks that never use the filter; the parity tests assert the branch is exercised. */
+  int64_t filter_undecided;
+  int64_t filter_fallback_steps;
+  /* ptx_render with n_gpus > 1 / ptx_render_multi: how each replica's raw sums reached the root device --
+   * peer_copies = device-to-device with peer access enabled (xGMI), staged_copies = hipMemcpyPeer without peer
+   * access (the runtime stages through host memory).  Replicas that share the root's device count in neither. */
+  int32_t peer_copies;
+  int32_t staged_copies;
 } ptx_stats;
 
 /* ---- progressive photon mapping (progressive-photon-map/src/progressive_photon_map.ml) ---- */

@@ -5,7 +5,7 @@ checks the sizes against the compiled library.
 """
 import ctypes as C
 
-PTX_ABI_VERSION = 1
+PTX_ABI_VERSION = 3
 
 PTX_MAT_LAMBERTIAN, PTX_MAT_METAL, PTX_MAT_DIELECTRIC = 0, 1, 2
 PTX_TEX_SOLID, PTX_TEX_CHECKER = 0, 1
@@ -66,6 +66,8 @@ class Stats(C.Structure):
         ("kernel_ms", C.c_double * PTX_N_KERNELS), ("kernel_launches", C.c_int64 * PTX_N_KERNELS),
         ("tree_nodes", C.c_int32), ("tree_depth", C.c_int32), ("tree_leaves", C.c_int32), ("leaf_slots", C.c_int32),
         ("build_ms", C.c_double), ("traversal_in_lds", C.c_int32), ("bvh_built_on_gpu", C.c_int32),
+        ("filter_undecided", C.c_int64), ("filter_fallback_steps", C.c_int64),
+        ("peer_copies", C.c_int32), ("staged_copies", C.c_int32),
     ]
 
 

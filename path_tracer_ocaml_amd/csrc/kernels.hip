@@ -93,6 +93,7 @@ __device__ __forceinline__ void pt_q_store(const PtQueue& q, uint32_t i, V3 o, V
 
 struct PtCounters { /* device-side work counters (count_work) */
   unsigned long long segments, nodes, prims, floor;
+  unsigned long long undecided, fallback_steps; /* binary32 filter: lane tests handed to the binary64 code, wave steps that ran it */
 };
 
 /* ------------------------------------------------------------------ small device helpers */
@@ -307,9 +308,6 @@ __device__ __forceinline__ bool pt_slab_hit_exact(const double* nb, V3 o, V3 inv
 /* bytes of LDS a wave keeps for traversal stacks: LDS-resident scenes walk the threaded image (no per-lane stack) and
  * only the camera-ray packet walk keeps its shared (node, mask) stack there: 12 bytes per level, rounded to 16 */
 #define PT_WAVE_STACK_BYTES(LDS_SCENE, StackT, depth) ((LDS_SCENE) ? (size_t)(depth) * 16u : (std::is_same<StackT, PtThreadTag>::value ? (size_t)0 : (size_t)(depth) * PT_WAVE * sizeof(StackT)))
-#ifndef PT_F32_FILTER_STATS
-#define PT_F32_FILTER_STATS 0 /* diagnostic: count undecided tests in the floor counter */
-#endif
 
 /* where the traversal data of this launch lives: HBM/L2 (large scenes) or an LDS copy (small scenes) */
 /* StackT of a walk that needs no stack: scenes traversed from HBM / L2 follow per-octant skip links like the LDS image
@@ -372,9 +370,7 @@ struct PtTraverser {
   /* binary32 filter constants of the ray (SWZ only): inv32, -(o * inv)32, k2 = 2^-19 max|inv|, c2 = max|o| k2 + 2^-21 t32 */
   float fix, fiy, fiz, fnx, fny, fnz, k2, c2base, c2, t32;
   uint32_t skip_off; /* SWZ: byte offset of this ray's octant entry in a node's skip table */
-#if PT_F32_FILTER_STATS
-  mutable unsigned long long n_undecided = 0, n_wave_fallbacks = 0;
-#endif
+  mutable unsigned long long n_undecided = 0, n_wave_fallbacks = 0; /* COUNT only (ptx_stats.filter_*) */
   double qa, one_over_a;
   PtTraceResult r;
   int sp;
@@ -401,8 +397,11 @@ struct PtTraverser {
       const double ax = pt_fabs(inv.x), ay = pt_fabs(inv.y), az = pt_fabs(inv.z);
       const double imax = __builtin_fmax(ax, __builtin_fmax(ay, az));
       const double omax = __builtin_fmax(pt_fabs(o.x), __builtin_fmax(pt_fabs(o.y), pt_fabs(o.z)));
-      /* every binary32 intermediate stays far inside the format: (mag + |o|) |inv| < 2^100 * 2^20 */
-      if (!(imax < 0x1p100) || !(omax < 0x1p20)) exact_slab = true;
+      /* every binary32 intermediate stays far inside the format: (mag + |o|) |inv| < 2^100 * 2^20.  And max|1/d| is kept
+       * far above the binary32 subnormals (>= 2^-60): components of inv32 / (o inv)32 that are subnormal -- or flushed to
+       * zero, whatever the f32 denormal mode of the code object -- are then wrong by < 2^-126 (mag + |o|) absolute, which
+       * m2 >= 2^-19 (mag + |o|) 2^-60 + 1e-30 covers with room to spare. */
+      if (!(imax < 0x1p100) || !(imax > 0x1p-60) || !(omax < 0x1p20)) exact_slab = true;
       fix = (float)inv.x; fiy = (float)inv.y; fiz = (float)inv.z;
       fnx = ORIGIN_ZERO ? 0.0f : -(float)(o.x * inv.x);
       fny = ORIGIN_ZERO ? 0.0f : -(float)(o.y * inv.y);
@@ -491,10 +490,10 @@ struct PtTraverser {
       hit = u >= m2;
       const bool undecided = active && (exact_slab || !(hit || u < -m2));
       if (__builtin_amdgcn_ballot_w64(undecided) != 0) {
-#if PT_F32_FILTER_STATS
-        if (undecided) n_undecided++;
-        if (pt_lane() == __ffsll((long long)__ballot(1)) - 1) n_wave_fallbacks++;
-#endif
+        if (COUNT) {
+          if (undecided) n_undecided++;
+          if (pt_lane() == __ffsll((long long)__ballot(1)) - 1) n_wave_fallbacks++;
+        }
         if (undecided) { /* the reference's arithmetic, on the binary64 node (global memory: L2-resident, rarely read) */
           const PtNode* np = sv.nodes + (SWZ ? nd / PT_SWZ_NODE_BYTES : nd);
           /* 1 / d again (the same three divisions as Ray.create): opaque to the optimiser, or it hoists them out of the
@@ -718,7 +717,8 @@ template <int MODE, bool COUNT, bool ORIGIN_ZERO, typename StackT, bool SWZ = fa
 __device__ __forceinline__ PtTraceResult pt_trace_ray(const PtSceneDev& sc, const PtSceneView& sv, StackT* stack,
                                                       V3 o, V3 d, unsigned long long& c_nodes,
                                                       unsigned long long& c_prims, unsigned long long& c_floor,
-                                                      bool valid = true, PtTailCtl* tc = nullptr) {
+                                                      bool valid = true, PtTailCtl* tc = nullptr,
+                                                      unsigned long long* c_filter = nullptr) {
   PtTraverser<MODE, COUNT, ORIGIN_ZERO, StackT, SWZ> tr;
   unsigned long long no_count = 0; /* lanes without a ray run begin() on a dummy ray: keep them out of the counters */
   /* a resumed walk has had its floor pre-test (its outcome is part of the parked state): not counted again */
@@ -752,9 +752,10 @@ __device__ __forceinline__ PtTraceResult pt_trace_ray(const PtSceneDev& sc, cons
     tc->unfinished = valid && tr.walking;
     tc->node = tr.node;
   }
-#if PT_F32_FILTER_STATS
-  if (COUNT && SWZ) { c_floor += tr.n_undecided; c_floor += tr.n_wave_fallbacks << 32; }
-#endif
+  if (COUNT && c_filter) {
+    c_filter[0] += tr.n_undecided;
+    c_filter[1] += tr.n_wave_fallbacks;
+  }
   return tr.r;
 }
 
@@ -771,7 +772,8 @@ __device__ __forceinline__ PtTraceResult pt_trace_ray(const PtSceneDev& sc, cons
 template <int MODE, bool COUNT, bool ORIGIN_ZERO, bool SWZ>
 __device__ __forceinline__ PtTraceResult pt_trace_packet(const PtSceneDev& sc, const PtSceneView& sv, uint32_t* wstack,
                                                          bool valid, V3 o, V3 d, unsigned long long& c_nodes,
-                                                         unsigned long long& c_prims, unsigned long long& c_floor) {
+                                                         unsigned long long& c_prims, unsigned long long& c_floor,
+                                                         unsigned long long* c_filter = nullptr) {
   const int lane = pt_lane();
   PtTraverser<MODE, COUNT, ORIGIN_ZERO, uint32_t, SWZ> tr;
   unsigned long long no_count = 0; /* lanes without a sample run begin() on a dummy ray: keep them out of the counters */
@@ -874,6 +876,10 @@ __device__ __forceinline__ PtTraceResult pt_trace_packet(const PtSceneDev& sc, c
         act = (pm >> lane) & 1ull;
       }
     }
+  }
+  if (COUNT && c_filter) {
+    c_filter[0] += tr.n_undecided;
+    c_filter[1] += tr.n_wave_fallbacks;
   }
   return tr.r;
 }
@@ -1065,7 +1071,7 @@ __global__ __launch_bounds__(PT_TRACE_BLOCK_OF(MODE, LDS_SCENE), (LDS_SCENE && M
   PtChunkFeed feed;
   feed.init(work, (uint32_t)(((unsigned long long)n + PT_WAVE - 1) / PT_WAVE), &lds_chunk_ctr);
   uint32_t chunk;
-  unsigned long long c_nodes = 0, c_prims = 0, c_floor = 0, c_seg = 0;
+  unsigned long long c_nodes = 0, c_prims = 0, c_floor = 0, c_seg = 0, c_filter[2] = {0, 0};
 
   if (PACKET) { /* the 64 rays of the wave walk the tree together (pt_trace_packet) */
     /* the wave's private stack area (stack_depth x 64 entries) holds the shared (node, mask) stack: 12 B per level */
@@ -1090,7 +1096,7 @@ __global__ __launch_bounds__(PT_TRACE_BLOCK_OF(MODE, LDS_SCENE), (LDS_SCENE && M
         }
       }
       if (COUNT && valid) c_seg++;
-      const PtTraceResult r = pt_trace_packet<MODE, COUNT, PRIMARY, LDS_SCENE>(sc, sv, wstack, valid, o, d, c_nodes, c_prims, c_floor);
+      const PtTraceResult r = pt_trace_packet<MODE, COUNT, PRIMARY, LDS_SCENE>(sc, sv, wstack, valid, o, d, c_nodes, c_prims, c_floor, c_filter);
       if (valid) {
         hits.t[i] = r.t;
         hits.slot[i] = r.slot;
@@ -1159,7 +1165,7 @@ __global__ __launch_bounds__(PT_TRACE_BLOCK_OF(MODE, LDS_SCENE), (LDS_SCENE && M
       tc.v = __hiloint2double((int)parked_uv.w, (int)parked_uv.z);
       tc.unfinished = false;
       /* every lane goes in (wave-level ballots inside); lanes without a ray commit nothing */
-      const PtTraceResult r = pt_trace_ray<MODE, COUNT, PRIMARY, StackT, LDS_SCENE>(sc, sv, stack, o, d, c_nodes, c_prims, c_floor, valid, TAIL ? &tc : nullptr);
+      const PtTraceResult r = pt_trace_ray<MODE, COUNT, PRIMARY, StackT, LDS_SCENE>(sc, sv, stack, o, d, c_nodes, c_prims, c_floor, valid, TAIL ? &tc : nullptr, c_filter);
       if (COUNT && PT_DIAG == 2 && !PRIMARY && valid) {
         unsigned long long m = c_nodes - diag_n0;
         for (int off = 32; off > 0; off >>= 1) {
@@ -1200,11 +1206,15 @@ __global__ __launch_bounds__(PT_TRACE_BLOCK_OF(MODE, LDS_SCENE), (LDS_SCENE && M
     c_prims = pt_wave_sum(c_prims);
     c_floor = pt_wave_sum(c_floor);
     c_seg = pt_wave_sum(c_seg);
+    c_filter[0] = pt_wave_sum(c_filter[0]);
+    c_filter[1] = pt_wave_sum(c_filter[1]);
     if (lane == 0) {
       atomicAdd(&counters->nodes, c_nodes);
       atomicAdd(&counters->prims, c_prims);
       atomicAdd(&counters->floor, c_floor);
       atomicAdd(&counters->segments, c_seg);
+      atomicAdd(&counters->undecided, c_filter[0]);
+      atomicAdd(&counters->fallback_steps, c_filter[1]);
     }
   }
 }
@@ -1297,11 +1307,14 @@ __global__ __launch_bounds__(PT_TRACE_BLOCK_OF(MODE, LDS_SCENE), PT_TRACE_GLOBAL
     c_prims = pt_wave_sum(c_prims);
     c_floor = pt_wave_sum(c_floor);
     c_seg = pt_wave_sum(c_seg);
+    const unsigned long long c_und = pt_wave_sum(tr.n_undecided), c_fb = pt_wave_sum(tr.n_wave_fallbacks);
     if (lane == 0) {
       atomicAdd(&counters->nodes, c_nodes);
       atomicAdd(&counters->prims, c_prims);
       atomicAdd(&counters->floor, c_floor);
       atomicAdd(&counters->segments, c_seg);
+      atomicAdd(&counters->undecided, c_und);
+      atomicAdd(&counters->fallback_steps, c_fb);
     }
   }
 }

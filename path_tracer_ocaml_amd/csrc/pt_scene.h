@@ -101,10 +101,11 @@ struct PtSceneDev {
   /* n_nodes x 8 (u16 node indices, 0xffff = none): per direction octant, the node visited after a node's subtree
    * (the threading of the LDS node image, kernels.hip); NULL when the tree has 65535 nodes or more */
   const uint16_t* node_skip;
+  /* the same threading with 32-bit node indices (0xffffffff = none): scenes walked from HBM / L2 */
   const uint32_t* node_skip32;
   /* n_nodes x 32 bytes: mn.xyz, mx.xyz rounded to binary32, a, b (leaf b: padded count | real count << 15 | tag): the filter
    * image of the walk from HBM / L2 -- half the bytes per visit of the 64-byte binary64 node, which only undecided tests read */
-  const void* nodes32; /* the same threading with 32-bit node indices (0xffffffff = none): scenes walked from HBM / L2 */
+  const void* nodes32;
   /* unit vector (camera space) along which the primitives' centres vary least = the normal of the scene's ground plane when it
    * has one.  A HEURISTIC sort key only (shade bins survivors by the elevation of the new direction above that plane, a
    * predictor of how long the next walk is); it never enters a pixel value. */

@@ -39,23 +39,27 @@ def test_struct_layouts_match_c(tmp_path):
     from path_tracer_ocaml_amd import abi
     src = tmp_path / "sz.c"
     src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "ptx.h"\nint main(void){'
-                   'printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\\n", sizeof(ptx_material), sizeof(ptx_texture),'
+                   'printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\\n", sizeof(ptx_material), sizeof(ptx_texture),'
                    'sizeof(ptx_camera), sizeof(ptx_background), sizeof(ptx_scene_desc), sizeof(ptx_render_params),'
                    'sizeof(ptx_stats), offsetof(ptx_scene_desc, camera), offsetof(ptx_scene_desc, leaf_kind),'
-                   'offsetof(ptx_stats, kernel_ms), offsetof(ptx_render_params, n_gpus));return 0;}\n')
+                   'offsetof(ptx_stats, kernel_ms), offsetof(ptx_render_params, n_gpus), offsetof(ptx_stats, filter_undecided),'
+                   'offsetof(ptx_stats, staged_copies));return 0;}\n')
     exe = tmp_path / "sz"
     subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
     got = [int(x) for x in subprocess.check_output([str(exe)]).split()]
     want = [C.sizeof(abi.Material), C.sizeof(abi.Texture), C.sizeof(abi.Camera), C.sizeof(abi.Background),
             C.sizeof(abi.SceneDesc), C.sizeof(abi.RenderParams), C.sizeof(abi.Stats), abi.SceneDesc.camera.offset,
-            abi.SceneDesc.leaf_kind.offset, abi.Stats.kernel_ms.offset, abi.RenderParams.n_gpus.offset]
+            abi.SceneDesc.leaf_kind.offset, abi.Stats.kernel_ms.offset, abi.RenderParams.n_gpus.offset,
+            abi.Stats.filter_undecided.offset, abi.Stats.staged_copies.offset]
     assert got == want
 
 
 def test_version_and_leaf_size():
     import path_tracer_ocaml_amd as P
     L = P.lib()
-    assert L.ptx_version() == 2  # 2: ptx_render_params.n_gpus, ptx_render_multi, ptx_scene_replicate, banded film
+    assert L.ptx_version() == 3  # 3: ptx_stats.filter_* / peer_copies / staged_copies; 2: n_gpus, ptx_render_multi, ptx_scene_replicate, banded film
+    from path_tracer_ocaml_amd import abi
+    assert abi.PTX_ABI_VERSION == 3
     assert L.ptx_leaf_size() == 16  # LEAF_SIZE, sphere-intersect-rs/src/lib.rs:13
 
 

@@ -48,3 +48,47 @@ def test_bench_refuses_to_run_without_a_gpu():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "0"], capture_output=True, text=True)
     assert r.returncode != 0
     assert "no CPU fallback" in (r.stderr + r.stdout)
+
+
+def _json_lines(text):
+    out = []
+    for line in text.splitlines():
+        line = line.strip()
+        if line.startswith("{") and line.endswith("}"):
+            try:
+                out.append(json.loads(line))
+            except ValueError:
+                pass
+    return out
+
+
+def test_bench_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher: the parent starts two fresh ranks through torch.distributed.run before
+    touching any GPU, relays rank 0's ONE JSON line and the exit code.  The rehearsal flag replaces the renderer (which
+    needs a GPU) by synthetic bands, so the launcher, the rendezvous and the band exchange run here on CPU."""
+    env = dict(os.environ)
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--rehearse-launch",
+                        "--steps", "2", "--warmup", "1", "--workload", "shirley_600x300_spp32_d8"],
+                       capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = _json_lines(r.stdout)
+    assert len(lines) == 1, r.stdout
+    assert lines[0]["n_gpus"] == 2 and lines[0]["steps"] == 2 and lines[0]["warmup"] == 1
+    assert lines[0]["value"] is None and lines[0]["rehearsal"]["bands_arrived_in_place"] is True
+
+
+def test_self_launched_ranks_refuse_to_run_without_a_gpu():
+    """Without the rehearsal flag the ranks are real: on a box with no GPU each one refuses, and the parent hands the
+    failure on (non-zero exit, no JSON line)."""
+    import torch
+    if torch.cuda.is_available():
+        return
+    env = dict(os.environ)
+    env.pop("WORLD_SIZE", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode != 0
+    assert "no CPU fallback" in (r.stderr + r.stdout)
+    assert _json_lines(r.stdout) == []

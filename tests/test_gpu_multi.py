@@ -143,3 +143,40 @@ def test_banded_film_reads_the_gathered_layout_in_place(P):
         assert torch.equal(a.view(torch.int64), b.view(torch.int64)) and bool(torch.isfinite(a).all())
     with pytest.raises(P.PtxError, match="pad_rows"):
         P.film_resolve_banded_device(0, 8, 64, 1, d_g.data_ptr(), 2, 8, 8, a.data_ptr())
+
+
+def test_replicas_on_one_device_count_neither_peer_nor_staged(P):
+    from path_tracer_ocaml_amd import host as H
+    w, h = 96, 64
+    hs = H.shirley_spheres(w, h)
+    scene = P.Scene(hs.ptr, 0, keepalive=hs)
+    reps = [scene, scene.replicate(0)]
+    _, st = P.render_multi(reps, w, h, 2, 4)
+    assert st["peer_copies"] == 0 and st["staged_copies"] == 0
+    reps[1].close()
+    scene.close()
+
+
+def test_peer_access_between_two_devices(P):
+    """The one exchange of the path on real hardware: a replica on device 1, its raw sums copied into the root's gathered
+    layout with peer access enabled in both directions (xGMI).  Needs two GPUs: SKIPPED, not passed, on a one-GPU box."""
+    from path_tracer_ocaml_amd import host as H
+    if P.lib().ptx_device_count() < 2:
+        pytest.skip("needs >= 2 HIP devices (the driver's multi-GPU node)")
+    w, h, spp, depth = 320, 200, 8, 8
+    hs = H.shirley_spheres(w, h)
+    scene = P.Scene(hs.ptr, 0, keepalive=hs)
+    single, st1 = scene.render(w, h, spp, depth, count_work=True)
+    n = min(P.lib().ptx_device_count(), 8)
+    reps = [scene] + [scene.replicate(k) for k in range(1, n)]
+    multi, stn = P.render_multi(reps, w, h, spp, depth, count_work=True)
+    assert np.array_equal(bits(single), bits(multi))
+    assert stn["peer_copies"] + stn["staged_copies"] == n - 1
+    assert stn["peer_copies"] == n - 1, "xGMI peer access was not granted between the devices of this node"
+    for k in ("samples", "segments", "nodes_tested", "prims_tested"):
+        assert stn[k] == st1[k], k
+    again, _ = scene.render(w, h, spp, depth, n_gpus=n)  # the same through ptx_render's n_gpus
+    assert np.array_equal(bits(single), bits(again))
+    for r in reps[1:]:
+        r.close()
+    scene.close()
