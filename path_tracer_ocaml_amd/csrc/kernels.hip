@@ -294,7 +294,8 @@ __device__ __forceinline__ bool pt_slab_hit_exact(const double* nb, V3 o, V3 inv
  *               stack pointer and no per-lane stack in LDS: ~12 fewer vector instructions and 1 LDS access less per visit.
  * Bbox.is_hit (bbox.ml:40-56) is a boolean of binary64 quantities; the image decides it in binary32 with a rigorous
  * error bound and hands the (rare) undecided lanes to the binary64 code, so the boolean -- and with it every hit, every
- * work counter and every pixel -- is the reference's.  For a ray with |1/d| < 2^100 (else: always binary64):
+ * work counter and every pixel -- is the reference's.  For a ray with (root_mag + max|o|) max|1/d| < 2^100 and
+ * max|1/d| > 2^-60 (else: always binary64):
  *   t~ = fma32(bound32, inv32, -(o * inv)32) differs from the reference's fl64((bound - o) * inv) by at most
  *        3.2 * 2^-24 * (|bound| + |o|) * |inv|  <=  M := 3.2 * 2^-24 * (mag + max|o|) * max|inv|
  *   (three binary32 roundings of the inputs, one of the fma, the reference's own two binary64 roundings);
@@ -397,11 +398,13 @@ struct PtTraverser {
       const double ax = pt_fabs(inv.x), ay = pt_fabs(inv.y), az = pt_fabs(inv.z);
       const double imax = __builtin_fmax(ax, __builtin_fmax(ay, az));
       const double omax = __builtin_fmax(pt_fabs(o.x), __builtin_fmax(pt_fabs(o.y), pt_fabs(o.z)));
-      /* every binary32 intermediate stays far inside the format: (mag + |o|) |inv| < 2^100 * 2^20.  And max|1/d| is kept
-       * far above the binary32 subnormals (>= 2^-60): components of inv32 / (o inv)32 that are subnormal -- or flushed to
-       * zero, whatever the f32 denormal mode of the code object -- are then wrong by < 2^-126 (mag + |o|) absolute, which
-       * m2 >= 2^-19 (mag + |o|) 2^-60 + 1e-30 covers with room to spare. */
-      if (!(imax < 0x1p100) || !(imax > 0x1p-60) || !(omax < 0x1p20)) exact_slab = true;
+      /* every binary32 intermediate stays far inside the format: (mag + |o|) |inv| < 2^100 for every node, because every
+       * node lies inside the root box (root_mag = its largest |coordinate|, +inf when that exceeds binary32: such a scene
+       * is walked in binary64 throughout), so no product, sum or margin of the filter can overflow, whatever the scene's
+       * scale.  And max|1/d| is kept far above the binary32 subnormals (>= 2^-60): components of inv32 / (o inv)32 that
+       * are subnormal -- or flushed to zero, whatever the f32 denormal mode of the code object -- are then wrong by
+       * < 2^-126 (mag + |o|) absolute, which m2 >= 2^-19 (mag + |o|) 2^-60 + 1e-30 covers with room to spare. */
+      if (!(((double)sc.root_mag + omax) * imax < 0x1p100) || !(imax > 0x1p-60)) exact_slab = true;
       fix = (float)inv.x; fiy = (float)inv.y; fiz = (float)inv.z;
       fnx = ORIGIN_ZERO ? 0.0f : -(float)(o.x * inv.x);
       fny = ORIGIN_ZERO ? 0.0f : -(float)(o.y * inv.y);

@@ -116,6 +116,11 @@ struct PtSceneDev {
    * that enters it walks a hundred nodes, and a wave that holds both waits for the longest.  Heuristic, binary32, never enters a pixel. */
   int32_t sort_by_root;
   float root_mn[3], root_mx[3];
+  /* max |coordinate| of the tree's root box, rounded UP to binary32 (+inf when it exceeds the format): every node lies inside
+   * the root box, so this bounds every node's magnitude.  The binary32 node filter applies to a ray only if
+   * (root_mag + max|o|) * max|1/d| < 2^100 -- then no binary32 intermediate of the filter can overflow (kernels.hip, begin()). */
+  float root_mag;
+  float pad_f;
   double cam_llx, cam_lly, cam_vx, cam_vy;
   int32_t bg_kind;
   int32_t pad0;
