@@ -3,19 +3,30 @@
  * ptx_stubs.c (which needs <caml/...> and cannot be compiled in this image) only unpacks OCaml values into the
  * FLAT view below -- borrowed pointers into floatarrays / Bigarrays, exactly the convention of the reference's
  * existing stub (value coords -> f64 slices read in place, sphere-intersect-rs/src/lib.rs:53-76) -- and calls
- * these two functions.  Everything that can go wrong between "flat OCaml data" and the C ABI of include/ptx.h
+ * these functions.  Everything that can go wrong between "flat OCaml data" and the C ABI of include/ptx.h
  * therefore lives here, where tests/test_ocaml_binding.py can compile and run it (gcc, no OCaml needed).
  *
- * Flat layout (what bindings/ocaml/ptx.ml produces):
- *   xs, ys, zs, rs     floatarray, one entry per sphere, CAMERA space (Sphere.transform ~f:(Camera.transform camera),
- *                      shirley_spheres/bin/main.ml:258-260)
+ * Flat layout (what bindings/ocaml/ptx.ml's `flatten` produces; every coordinate in CAMERA space):
+ *   xs, ys, zs, rs     floatarray, one entry per sphere (Sphere.transform ~f:(Camera.transform camera),
+ *                      shirley_spheres/bin/main.ml:258-260; cornell-box/bin/main.ml:70-91,218)
  *   sphere_material    int32 Bigarray, index into `materials`
  *   materials          floatarray, 6 per material : kind (0 Lambertian, 1 Metal, 2 Dielectric), texture index,
- *                      refraction index, emit r g b          (Material.t, path_tracer/src/material.ml:3-14)
+ *                      refraction index, emit r g b          (Material.t, path_tracer/src/material.ml:3-14; Hit.emit, hit.ml:5)
  *   textures           floatarray, 9 per texture  : kind (0 solid, 1 checker), width, height, even r g b, odd r g b
  *                      (Texture.solid / Texture.checker, path_tracer/src/texture.ml:16-31)
  *   camera             floatarray, 4 : lower_left_x, lower_left_y, view_x, view_y   (camera.ml:50-53)
  *   background         floatarray, 7 : kind (0 black, 1 sky), horizon r g b, zenith r g b  (main.ml:104-110)
+ *   vertex_x/y/z       floatarray, one entry per mesh vertex (ganesha Mesh.t, ganesha/bin/main.ml:37-85; cornell-box's
+ *                      Face.t keeps three private vertices per triangle, cornell-box/bin/main.ml:5-28)
+ *   tri_indices        int32 Bigarray, 3 per triangle: a, b, c (ganesha Face.t, main.ml:92-110)
+ *   tri_uv             floatarray, 6 per triangle: Face.tex_coords (ua, va), (ub, vb), (uc, vc)
+ *   tri_material       int32 Bigarray, 1 per triangle, index into `materials`
+ *   floor_vertices     floatarray, 9 per floor triangle: a, b, c -- tested BEFORE the tree, first hit clips t_max
+ *                      (ganesha Floor.intersect, main.ml:205-260,286-298)
+ *   floor_uv, floor_material   6 per floor triangle / int32 per floor triangle
+ *   lights             floatarray, 11 per light: kind (0 point, 1 spot), position xyz, direction xyz, color rgb, power
+ *                      (Progressive_photon_map.Light.create_point / create_spot, progressive_photon_map.ml:59-137)
+ *   ppm params         floatarray, 6: width, height, iterations, max_bounces, photon_count, alpha (Args.t, :7-16)
  */
 #ifndef PTX_ML_MARSHAL_H
 #define PTX_ML_MARSHAL_H
@@ -36,13 +47,24 @@ typedef struct ptx_ml_flat {
   const double* textures;  /* 9 per texture */
   const double* camera;     /* 4 */
   const double* background; /* 7 */
-  int32_t leaf_kind;        /* PTX_LEAF_SIMD (Simd_leaf) / PTX_LEAF_ARRAY (Array_leaf, --no-simd) */
-  int32_t length_cutoff;    /* Leaf.length_cutoff: leaf_size () = 16 / 4 (main.ml:121,175) */
+  int32_t leaf_kind;        /* PTX_LEAF_SIMD (Simd_leaf) / PTX_LEAF_ARRAY (Array_leaf) */
+  int32_t length_cutoff;    /* Leaf.length_cutoff: leaf_size () = 16 / 4 (main.ml:121,175) / 2 (cornell) / 8 (ganesha) */
+  /* triangle mesh: all zero / NULL when the scene has none */
+  int32_t n_vertices;
+  const double *vertex_x, *vertex_y, *vertex_z;
+  int32_t n_triangles;
+  const int32_t* tri_indices; /* 3 per triangle */
+  const double* tri_uv;       /* 6 per triangle */
+  const int32_t* tri_material;
+  int32_t n_floor_triangles;
+  const double* floor_vertices; /* 9 per triangle */
+  const double* floor_uv;       /* 6 per triangle */
+  const int32_t* floor_material;
 } ptx_ml_flat;
 
 /* NULL + ptx_last_error() on failure, like ptx_scene_create.  Nothing of `f` is referenced after the call returns. */
 static ptx_scene* ptx_ml_scene_create(const ptx_ml_flat* f, int32_t device) {
-  if (!f || f->n_spheres < 0 || f->n_materials <= 0 || f->n_textures < 0) return NULL;
+  if (!f || f->n_spheres < 0 || f->n_triangles < 0 || f->n_floor_triangles < 0 || f->n_materials <= 0 || f->n_textures < 0) return NULL;
   ptx_material* mats = (ptx_material*)calloc((size_t)f->n_materials, sizeof *mats);
   ptx_texture* texs = (ptx_texture*)calloc((size_t)(f->n_textures > 0 ? f->n_textures : 1), sizeof *texs);
   if (!mats || !texs) {
@@ -70,6 +92,16 @@ static ptx_scene* ptx_ml_scene_create(const ptx_ml_flat* f, int32_t device) {
   d.n_spheres = f->n_spheres;
   d.sphere_x = f->xs; d.sphere_y = f->ys; d.sphere_z = f->zs; d.sphere_r = f->rs;
   d.sphere_material = f->sphere_material;
+  d.n_vertices = f->n_vertices;
+  d.vertex_x = f->vertex_x; d.vertex_y = f->vertex_y; d.vertex_z = f->vertex_z;
+  d.n_triangles = f->n_triangles;
+  d.tri_indices = f->tri_indices;
+  d.tri_uv = f->tri_uv;
+  d.tri_material = f->tri_material;
+  d.n_floor_triangles = f->n_floor_triangles;
+  d.floor_vertices = f->floor_vertices;
+  d.floor_uv = f->floor_uv;
+  d.floor_material = f->floor_material;
   d.n_materials = f->n_materials;
   d.materials = mats;
   d.n_textures = f->n_textures;
@@ -99,6 +131,33 @@ static int32_t ptx_ml_render(ptx_scene* s, int32_t width, int32_t height, int32_
   p.max_bounces = max_bounces;
   p.n_gpus = n_gpus;
   return ptx_render(s, &p, image, NULL, progress, user);
+}
+
+/* Progressive_photon_map.Make(Scene).go's loop (progressive_photon_map.ml:420-451) without the prints and the PNG:
+ * params6 = width, height, iterations, max_bounces, photon_count, alpha; lights11 = 11 doubles per light (above).
+ * img_sum (W*H*3) receives the final sum; iteration_cb gets the running sum after every iteration. */
+static int32_t ptx_ml_ppm_render(ptx_scene* s, const double* params6, const double* lights11, int32_t n_lights, double* img_sum,
+                                 ptx_ppm_iteration_fn iteration_cb, void* user) {
+  if (!params6 || n_lights < 0 || n_lights > 64 || (n_lights > 0 && !lights11)) return -1;
+  ptx_ppm_params p;
+  memset(&p, 0, sizeof p);
+  p.width = (int32_t)params6[0];
+  p.height = (int32_t)params6[1];
+  p.iterations = (int32_t)params6[2];
+  p.max_bounces = (int32_t)params6[3];
+  p.photon_count = (int32_t)params6[4];
+  p.alpha = params6[5];
+  ptx_light lights[64];
+  memset(lights, 0, sizeof lights);
+  for (int32_t i = 0; i < n_lights; ++i) {
+    const double* l = lights11 + 11 * (size_t)i;
+    lights[i].kind = (int32_t)l[0];
+    memcpy(lights[i].position, l + 1, sizeof lights[i].position);
+    memcpy(lights[i].direction, l + 4, sizeof lights[i].direction);
+    memcpy(lights[i].color, l + 7, sizeof lights[i].color);
+    lights[i].power = l[10];
+  }
+  return ptx_ppm_render(s, &p, lights, n_lights, img_sum, NULL, iteration_cb, user);
 }
 
 #endif /* PTX_ML_MARSHAL_H */

@@ -5,8 +5,9 @@
  * and linked by shirley_spheres/bin/dune:8-33): plain `external` C symbols, OCaml values unpacked by hand, pointers
  * BORROWED for the duration of the call -- but one call per render instead of one per BVH leaf per ray.
  *
- * Needs the OCaml runtime headers (<caml/...>), so it is not compiled in this repository's image; the marshalling it
- * performs lives in ptx_ml_marshal.h and is exercised without OCaml by tests/test_ocaml_binding.py.
+ * Needs the OCaml runtime headers (<caml/...>), so it is not compiled into anything in this repository's image; the
+ * marshalling it performs lives in ptx_ml_marshal.h and is exercised without OCaml by tests/test_ocaml_binding.py, which
+ * also type-checks THIS file (gcc -fsyntax-only) against minimal declarations of the runtime's API (tests/c/mock_caml).
  *
  * Value conventions:
  *   floatarray          Double_array_tag block: (double*) v is the flat data, Wosize_val(v) / Double_wosize the length
@@ -15,8 +16,12 @@
  *   int                 Long_val / Val_long
  *   scene handle        custom block holding the ptx_scene*, finalised with ptx_scene_destroy
  *   errors              caml_failwith (ptx_last_error ()): no error code ever reaches OCaml unraised
- *   progress closure    called through caml_callback on the CALLING thread (ptx_render's contract), so the runtime lock
- *                       is held and no foreign thread ever touches the OCaml heap
+ *   callbacks           update_progress / on_iteration run on the CALLING thread (the library's contract).  The runtime
+ *                       lock is RELEASED for the duration of the render (other domains and threads keep running; the
+ *                       reference's own integrator leaves them running too) and re-taken around each callback.  A
+ *                       callback that raises does not unwind through the library's C++ frames: the exception is caught
+ *                       (caml_callback_exn), kept, no further callbacks are made, and it is re-raised after the library
+ *                       call has returned.
  */
 #define CAML_NAME_SPACE
 #include <caml/alloc.h>
@@ -26,6 +31,7 @@
 #include <caml/fail.h>
 #include <caml/memory.h>
 #include <caml/mlvalues.h>
+#include <caml/threads.h>
 
 #include "ptx_ml_marshal.h"
 
@@ -44,6 +50,8 @@ static struct custom_operations ptx_ml_scene_ops = {
 
 static const double* floatarray_data(value v) { return (const double*)v; }
 static int32_t floatarray_length(value v) { return (int32_t)(Wosize_val(v) / Double_wosize); }
+static int32_t int32_ba_length(value v) { return (int32_t)Caml_ba_array_val(v)->dim[0]; }
+static const int32_t* int32_ba_data(value v) { return (const int32_t*)Caml_ba_data_val(v); }
 
 /* external leaf_size : unit -> int = "ptx_ml_leaf_size"   (replaces `leaf_size`, lib.rs:15-18) */
 CAMLprim value ptx_ml_leaf_size(value unit) {
@@ -57,22 +65,24 @@ CAMLprim value ptx_ml_device_count(value unit) {
   return Val_long(ptx_device_count());
 }
 
-/* external scene_create : flat -> int -> scene = "ptx_ml_scene_create_stub"
- * flat = { xs; ys; zs; rs; sphere_material; materials; textures; camera; background; leaf_kind; length_cutoff }
+/* external scene_create_flat : flat -> int -> scene = "ptx_ml_scene_create_stub"
+ * flat = { xs; ys; zs; rs; sphere_material; materials; textures; camera; background; leaf_kind; length_cutoff;
+ *          vertex_x; vertex_y; vertex_z; tri_indices; tri_uv; tri_material; floor_vertices; floor_uv; floor_material }
  * (field order of Ptx.flat in ptx.ml) */
 CAMLprim value ptx_ml_scene_create_stub(value flat, value device) {
   CAMLparam2(flat, device);
   CAMLlocal1(handle);
   ptx_ml_flat f;
+  memset(&f, 0, sizeof f);
   f.xs = floatarray_data(Field(flat, 0));
   f.ys = floatarray_data(Field(flat, 1));
   f.zs = floatarray_data(Field(flat, 2));
   f.rs = floatarray_data(Field(flat, 3));
   f.n_spheres = floatarray_length(Field(flat, 0));
   if (floatarray_length(Field(flat, 1)) != f.n_spheres || floatarray_length(Field(flat, 2)) != f.n_spheres ||
-      floatarray_length(Field(flat, 3)) != f.n_spheres || Caml_ba_array_val(Field(flat, 4))->dim[0] != f.n_spheres)
+      floatarray_length(Field(flat, 3)) != f.n_spheres || int32_ba_length(Field(flat, 4)) != f.n_spheres)
     caml_invalid_argument("Ptx.scene_create: sphere arrays differ in length");
-  f.sphere_material = (const int32_t*)Caml_ba_data_val(Field(flat, 4));
+  f.sphere_material = int32_ba_data(Field(flat, 4));
   f.materials = floatarray_data(Field(flat, 5));
   f.n_materials = floatarray_length(Field(flat, 5)) / 6;
   f.textures = floatarray_data(Field(flat, 6));
@@ -83,7 +93,29 @@ CAMLprim value ptx_ml_scene_create_stub(value flat, value device) {
   f.background = floatarray_data(Field(flat, 8));
   f.leaf_kind = (int32_t)Long_val(Field(flat, 9));
   f.length_cutoff = (int32_t)Long_val(Field(flat, 10));
-  /* no OCaml allocation between reading the pointers above and the end of ptx_ml_scene_create: nothing can move */
+  /* the triangle mesh (ganesha Mesh.t / cornell-box Face.t) */
+  f.n_vertices = floatarray_length(Field(flat, 11));
+  if (floatarray_length(Field(flat, 12)) != f.n_vertices || floatarray_length(Field(flat, 13)) != f.n_vertices)
+    caml_invalid_argument("Ptx.scene_create: vertex arrays differ in length");
+  f.vertex_x = floatarray_data(Field(flat, 11));
+  f.vertex_y = floatarray_data(Field(flat, 12));
+  f.vertex_z = floatarray_data(Field(flat, 13));
+  f.n_triangles = int32_ba_length(Field(flat, 14)) / 3;
+  if (int32_ba_length(Field(flat, 14)) != 3 * f.n_triangles || floatarray_length(Field(flat, 15)) != 6 * f.n_triangles ||
+      int32_ba_length(Field(flat, 16)) != f.n_triangles)
+    caml_invalid_argument("Ptx.scene_create: a mesh needs 3 indices, 6 texture coordinates and 1 material per triangle");
+  f.tri_indices = int32_ba_data(Field(flat, 14));
+  f.tri_uv = floatarray_data(Field(flat, 15));
+  f.tri_material = int32_ba_data(Field(flat, 16));
+  /* triangles tested before the tree (ganesha Floor) */
+  f.n_floor_triangles = int32_ba_length(Field(flat, 19));
+  if (floatarray_length(Field(flat, 17)) != 9 * f.n_floor_triangles || floatarray_length(Field(flat, 18)) != 6 * f.n_floor_triangles)
+    caml_invalid_argument("Ptx.scene_create: a floor triangle needs 9 coordinates and 6 texture coordinates");
+  f.floor_vertices = floatarray_data(Field(flat, 17));
+  f.floor_uv = floatarray_data(Field(flat, 18));
+  f.floor_material = int32_ba_data(Field(flat, 19));
+  /* no OCaml allocation between reading the pointers above and the end of ptx_ml_scene_create: nothing can move
+   * (the runtime lock stays held here: the floatarrays live in the OCaml heap) */
   ptx_scene* s = ptx_ml_scene_create(&f, (int32_t)Long_val(device));
   if (!s) caml_failwith(ptx_last_error());
   handle = caml_alloc_custom(&ptx_ml_scene_ops, sizeof(ptx_scene*), 0, 1);
@@ -97,31 +129,127 @@ CAMLprim value ptx_ml_scene_destroy_stub(value handle) {
   return Val_unit;
 }
 
-static void ptx_ml_progress(void* user, int64_t pixels_done) {
-  /* `user` points at a GC root registered by the caller below; the closure may allocate */
-  caml_callback(*(value*)user, Val_long(pixels_done));
+/* external scene_tree_stats : scene -> int * int * int * int = "ptx_ml_scene_tree_stats_stub"   (depth, nodes, leaves, slots) */
+CAMLprim value ptx_ml_scene_tree_stats_stub(value handle) {
+  CAMLparam1(handle);
+  CAMLlocal1(tuple);
+  ptx_scene* s = Scene_val(handle);
+  if (!s) caml_invalid_argument("Ptx.scene_tree_stats: scene already destroyed");
+  ptx_stats st;
+  if (ptx_scene_stats(s, &st) != 0) caml_failwith(ptx_last_error());
+  tuple = caml_alloc_tuple(4);
+  Store_field(tuple, 0, Val_long(st.tree_depth));
+  Store_field(tuple, 1, Val_long(st.tree_nodes));
+  Store_field(tuple, 2, Val_long(st.tree_leaves));
+  Store_field(tuple, 3, Val_long(st.leaf_slots));
+  CAMLreturn(tuple);
 }
 
-/* external render : scene -> int -> int -> int -> int -> int -> image -> (int -> unit) -> unit
- *   = "ptx_ml_render_bytecode" "ptx_ml_render"
+/* What a callback trampoline needs: the closure (a GC root registered by the stub that owns this struct) and the first
+ * exception a callback raised.  While `raised` is set no further callbacks are made. */
+typedef struct ptx_ml_cb {
+  value* closure;
+  value* exn; /* GC root; Val_unit until a callback raises */
+  int raised;
+} ptx_ml_cb;
+
+static void ptx_ml_progress(void* user, int64_t pixels_done) {
+  ptx_ml_cb* cb = (ptx_ml_cb*)user;
+  if (cb->raised) return;
+  caml_acquire_runtime_system(); /* the render runs with the lock released */
+  value r = caml_callback_exn(*cb->closure, Val_long(pixels_done));
+  if (Is_exception_result(r)) {
+    *cb->exn = Extract_exception(r);
+    cb->raised = 1;
+  }
+  caml_release_runtime_system();
+}
+
+/* external render_flat : scene -> int -> int -> int -> int -> int -> image -> (int -> unit) -> unit
+ *   = "ptx_ml_render_stub_bytecode" "ptx_ml_render_stub"
  * (scene, width, height, samples_per_pixel, max_bounces, gpus, Bimage data as a float64 Bigarray of W*H*3, update_progress)
  * replaces Integrator.create ... |> Integrator.render ~update_progress (render_command.ml:71-104) */
-CAMLprim value ptx_ml_render(value handle, value width, value height, value spp, value max_bounces, value gpus, value image,
-                             value update_progress) {
+CAMLprim value ptx_ml_render_stub(value handle, value width, value height, value spp, value max_bounces, value gpus, value image,
+                                  value update_progress) {
   CAMLparam5(handle, width, height, spp, max_bounces);
   CAMLxparam3(gpus, image, update_progress);
+  CAMLlocal1(exn);
   ptx_scene* s = Scene_val(handle);
   if (!s) caml_invalid_argument("Ptx.render: scene already destroyed");
   const intnat w = Long_val(width), h = Long_val(height);
   if (Caml_ba_array_val(image)->dim[0] != w * h * 3) caml_invalid_argument("Ptx.render: image must hold width * height * 3 floats");
-  double* out = (double*)Caml_ba_data_val(image); /* Bigarray data lives outside the OCaml heap: stable across callbacks */
-  const int32_t rc = ptx_ml_render(s, (int32_t)w, (int32_t)h, (int32_t)Long_val(spp), (int32_t)Long_val(max_bounces),
-                                   (int32_t)Long_val(gpus), out, ptx_ml_progress, &update_progress);
+  double* out = (double*)Caml_ba_data_val(image); /* Bigarray data lives outside the OCaml heap: stable while the lock is released */
+  const int32_t i_spp = (int32_t)Long_val(spp), i_mb = (int32_t)Long_val(max_bounces), i_gpus = (int32_t)Long_val(gpus);
+  exn = Val_unit;
+  ptx_ml_cb cb = {&update_progress, &exn, 0};
+  caml_release_runtime_system();
+  const int32_t rc = ptx_ml_render(s, (int32_t)w, (int32_t)h, i_spp, i_mb, i_gpus, out, ptx_ml_progress, &cb);
+  caml_acquire_runtime_system();
+  if (cb.raised) caml_raise(exn); /* update_progress raised: the render completed, its exception surfaces here */
   if (rc != 0) caml_failwith(ptx_last_error());
   CAMLreturn(Val_unit);
 }
 
-CAMLprim value ptx_ml_render_bytecode(value* argv, int argn) {
+CAMLprim value ptx_ml_render_stub_bytecode(value* argv, int argn) {
   (void)argn;
-  return ptx_ml_render(argv[0], argv[1], argv[2], argv[3], argv[4], argv[5], argv[6], argv[7]);
+  return ptx_ml_render_stub(argv[0], argv[1], argv[2], argv[3], argv[4], argv[5], argv[6], argv[7]);
+}
+
+/* runs with the runtime lock held */
+static void ptx_ml_call_on_iteration(ptx_ml_cb* cb, int32_t iteration, double radius, int64_t photon_map_length) {
+  CAMLparam0();
+  CAMLlocal2(boxed_radius, r);
+  boxed_radius = caml_copy_double(radius);
+  r = caml_callback3_exn(*cb->closure, Val_long(iteration), boxed_radius, Val_long(photon_map_length));
+  if (Is_exception_result(r)) {
+    *cb->exn = Extract_exception(r);
+    cb->raised = 1;
+  }
+  CAMLreturn0;
+}
+
+/* the iteration callback of the library hands over ITS host copy of the running sum; the OCaml side reads its own Bigarray
+ * (save_image reads img_sum.data, progressive_photon_map.ml:406-418), so the sum is copied there first */
+typedef struct ptx_ml_ppm_cb {
+  ptx_ml_cb cb;
+  double* img_sum;
+  size_t n;
+} ptx_ml_ppm_cb;
+
+static void ptx_ml_on_iteration_copy(void* user, int32_t iteration, double radius, int64_t photon_map_length, const double* img_sum) {
+  ptx_ml_ppm_cb* p = (ptx_ml_ppm_cb*)user;
+  if (p->cb.raised) return;
+  memcpy(p->img_sum, img_sum, sizeof(double) * p->n);
+  caml_acquire_runtime_system(); /* the render runs with the lock released */
+  ptx_ml_call_on_iteration(&p->cb, iteration, radius, photon_map_length);
+  caml_release_runtime_system();
+}
+
+/* external ppm_render_flat : scene -> floatarray -> floatarray -> img_sum -> (int -> float -> int -> unit) -> unit
+ *   = "ptx_ml_ppm_render_stub"
+ * replaces the loop of Progressive_photon_map.Make(Scene).go (progressive_photon_map.ml:433-450) */
+CAMLprim value ptx_ml_ppm_render_stub(value handle, value params, value lights, value img_sum, value on_iteration) {
+  CAMLparam5(handle, params, lights, img_sum, on_iteration);
+  CAMLlocal1(exn);
+  ptx_scene* s = Scene_val(handle);
+  if (!s) caml_invalid_argument("Ptx.ppm_render: scene already destroyed");
+  if (floatarray_length(params) != 6) caml_invalid_argument("Ptx.ppm_render: params needs 6 floats");
+  const int32_t n_lights = floatarray_length(lights) / 11;
+  if (floatarray_length(lights) != 11 * n_lights || n_lights < 1 || n_lights > 64)
+    caml_invalid_argument("Ptx.ppm_render: 1 to 64 lights of 11 floats each");
+  /* params / lights live in the OCaml heap and the lock is about to be released: copy them out */
+  double p6[6], l11[64 * 11];
+  memcpy(p6, floatarray_data(params), sizeof p6);
+  memcpy(l11, floatarray_data(lights), sizeof(double) * 11 * (size_t)n_lights);
+  const intnat w = (intnat)p6[0], h = (intnat)p6[1];
+  if (w <= 0 || h <= 0 || Caml_ba_array_val(img_sum)->dim[0] != w * h * 3)
+    caml_invalid_argument("Ptx.ppm_render: img_sum must hold width * height * 3 floats");
+  exn = Val_unit;
+  ptx_ml_ppm_cb cb = {{&on_iteration, &exn, 0}, (double*)Caml_ba_data_val(img_sum), (size_t)(w * h * 3)};
+  caml_release_runtime_system();
+  const int32_t rc = ptx_ml_ppm_render(s, p6, l11, n_lights, cb.img_sum, ptx_ml_on_iteration_copy, &cb);
+  caml_acquire_runtime_system();
+  if (cb.cb.raised) caml_raise(exn);
+  if (rc != 0) caml_failwith(ptx_last_error());
+  CAMLreturn(Val_unit);
 }

@@ -53,7 +53,7 @@ def test_ganesha_cli_renders_a_ply_file(P, oracle, tmp_path):
     d.d.background.kind = abi.PTX_BG_BLACK
     o = oracle.Scene(d.ptr, d)
     o_img, o_st = o.ppm_render(abi.ppm_params(w, h, iterations=iters, photon_count=photons), o.lights_ganesha())
-    assert o_st["neighbors"] > 10000 and o_img.max() > 0
+    assert o_st["neighbors"] > 1000 and o_img.max() > 0
     want = np.clip(H.ppm_gamma(o_img, iters) * 255.0, 0, 255).astype(np.uint8)
     got = np.array(Image.open(out).convert("RGB"))
     assert got.shape == want.shape
