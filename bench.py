@@ -373,7 +373,7 @@ def main():
                         "unit": "TFLOP/s", "frac": flops_achieved / (F64_VECTOR_PEAK_TFLOPS * world), "traffic": traffic,
                         "algorithmic_flop_per_launch": alg_flop / n_launch,
                         "flop_model": f"{FLOP_PER_NODE_TEST:g} per Bbox.is_hit + {FLOP_PER_SLOT_SCAN:g} per packet slot scanned (reference arithmetic, binary64)",
-                        "issue": {k: tc.get(k) for k in ("valu_busy", "lane_util", "useful_issue_frac", "lds_busy", "lds_bank_conflict_share", "source")},
+                        "issue": {k: tc.get(k) for k in ("valu_busy", "valu_issue_from_insts", "lane_util", "useful_issue_frac", "lds_busy", "lds_bank_conflict_share", "duration_cycles_source", "source")},
                         "hbm": hbm_block}
         else:
             roofline = {"bound": "hbm", "kernel": "k_trace / k_trace_stream", "achieved": bytes_achieved, "peak": HBM_PEAK_GBS * world,
@@ -411,14 +411,23 @@ def main():
                                  "frac": valu_ms / ms_per_step if ms_per_step > 0 else None,
                                  "valu_busy_share": {"trace": vb_t, "shade": vb_s}, "source": tc.get("source"),
                                  "note": "vector-pipe busy time of the step's kernels (one-stream durations x tracked counter shares) / the step"}
+        # frame-level HBM traffic: counter-measured bytes of every kernel of a step (tracked profile) over the step as timed here
+        hb = tc.get("hbm_bytes_per_step")
+        if hb:
+            roofline["hbm_frame"] = {"bound": "hbm", "traffic_per_step": hb, "achieved": hb / (ms_per_step * 1e-3) * 1e-9, "peak": HBM_PEAK_GBS * world,
+                                     "unit": "GB/s", "frac": hb / (ms_per_step * 1e-3) * 1e-9 / (HBM_PEAK_GBS * world), "peak_measured_copy": copy_gbs,
+                                     "by_stage": tc.get("hbm_bytes_per_step_by_stage"), "source": tc.get("source"),
+                                     "note": "sum over the step's kernels of rocprofv3 counter bytes (2 x FETCH_SIZE + WRITE_SIZE) x launches, from the tracked profile"}
         # the host-framebuffer entry point the CLI and the OCaml stub call (one 24 B/pixel device-to-host copy more)
         try:
-            scene.render(w, h, spp, depth)
+            import numpy as np
+            fb = np.zeros((h, w, 3))  # the caller's image, allocated and touched once like the reference's Bimage
+            scene.render(w, h, spp, depth, out=fb)
             t2 = time.perf_counter()
-            scene.render(w, h, spp, depth)
+            scene.render(w, h, spp, depth, out=fb)
             host_ms = (time.perf_counter() - t2) * 1e3
             host_api = {"ptx_render_ms": host_ms, "msamples_per_s": samples / host_ms * 1e-3,
-                        "note": "ptx_render: whole frame on this GPU, post-gamma framebuffer copied to host memory"} if world == 1 else None
+                        "note": "ptx_render: whole frame on this GPU, post-gamma framebuffer copied into the caller's host image (PCIe inclusive: never `value`)"} if world == 1 else None
         except Exception as e:
             host_api = {"ptx_render_ms": None, "note": f"unavailable: {e}"}
         out = {
@@ -432,6 +441,7 @@ def main():
                        "tree_nodes": sstats["tree_nodes"], "tree_depth": sstats["tree_depth"], "leaf_slots": sstats["leaf_slots"]},
             "roofline": roofline,
             "kernel_ms_per_step": dict(kernel_ms, one_stream_step_ms=one_stream_ms),
+            "kernel_launches_per_step": launches,
             "host_api": host_api,
             "work": {**counts, "segments_per_sample": counts["segments"] / samples,
                      "nodes_per_segment": counts["nodes_tested"] / max(counts["segments"], 1),

@@ -169,10 +169,14 @@ class Scene:
         assert got == n
         return bbox, info, order[:slots]
 
-    def render(self, width, height, samples_per_pixel, max_bounces, progress=None, **kw):
-        """ptx_render: post-gamma f64 framebuffer (H, W, 3) on the host + stats."""
+    def render(self, width, height, samples_per_pixel, max_bounces, progress=None, out=None, **kw):
+        """ptx_render: post-gamma f64 framebuffer (H, W, 3) on the host + stats.  `out`: the caller's (H, W, 3) float64
+        C-contiguous array to fill (the reference renders into the Bimage it was given, render_command.ml:65)."""
         p = render_params(width, height, samples_per_pixel, max_bounces, **kw)
-        out = np.zeros((height, width, 3))
+        if out is None:
+            out = np.zeros((height, width, 3))
+        elif out.shape != (height, width, 3) or out.dtype != np.float64 or not out.flags["C_CONTIGUOUS"]:
+            raise ValueError("out must be a C-contiguous float64 array of shape (height, width, 3)")
         st = abi.Stats()
         cb = PROGRESS_FN(lambda user, n: progress(n)) if progress else None
         _check(lib().ptx_render(self._h, C.byref(p), _dp(out), C.byref(st), C.cast(cb, C.c_void_p) if cb else None, None))

@@ -40,10 +40,18 @@ struct PtQueue {
 };
 
 struct PtHits {
-  double* t;
+  double* t;     /* scenes without triangles: t_hit per entry */
   int32_t* slot; /* leaf slot index, -1 = miss; >= n_slots = floor triangle */
-  double *u, *v; /* triangle barycentrics (triangle.ml:14-20); only with triangles */
+  /* scenes with triangles: ONE 32-byte record {t_hit, u, v, -} per entry (triangle barycentrics, triangle.ml:14-20) instead of
+   * three arrays -- the shade stage gathers an entry's hit sparsely (one category at a time), and three 8-byte reads from three
+   * arrays cost three 32-byte sectors where the record costs one.  `t` is then unused (NULL). */
+  double4* tuv;
 };
+__device__ __forceinline__ void pt_hit_store(const PtHits& hits, uint32_t i, double t, int slot, double u, double v, bool with_uv) {
+  hits.slot[i] = slot;
+  if (with_uv) hits.tuv[i] = make_double4(t, u, v, 0.0);
+  else hits.t[i] = t;
+}
 
 /* A queue written by k_shade_pool has HOLES (unused entries of its last blocks): direction x = a NaN whose payload no
  * arithmetic produces.  k_trace skips a hole and records PT_SLOT_HOLE for it. */
@@ -98,6 +106,10 @@ struct PtCounters { /* device-side work counters (count_work) */
 
 /* ------------------------------------------------------------------ small device helpers */
 __device__ __forceinline__ int pt_lane() { return (int)(threadIdx.x & 63); }
+
+/* popcount of a wave mask as a 32-bit scalar: `(int)__popcll(m) < K` is turned into a 64-bit comparison, for which the scalar
+ * unit has no instruction -- it lands on the VECTOR pipe, once per turn of the walk */
+__device__ __forceinline__ int pt_popc_mask(unsigned long long m) { return __builtin_popcount((unsigned)m) + __builtin_popcount((unsigned)(m >> 32)); }
 
 /* wave-aggregated append: returns the destination index for lanes with keep != 0 */
 __device__ __forceinline__ uint32_t pt_wave_append(uint32_t* counter, bool keep) {
@@ -302,9 +314,20 @@ __device__ __forceinline__ bool pt_slab_hit_exact(const double* nb, V3 o, V3 inv
  *   max / min are 1-Lipschitz, so lo~ = max(0, a~) and hi~ = min(b~, t32) are within M (+ 2^-24 t for the rounded
  *   closest-hit distance) of the reference's lo, hi, and u = hi~ - lo~ (one more rounding) within 8.4 * 2^-24 * (..)
  *   + 2^-24 t of hi - lo.  With m2 = 2^-19 * (mag + max|o|) * max|inv| + 2^-21 * t32  (twice that bound):
- *        u >= m2  =>  lo <= hi (hit)        u < -m2  =>  lo > hi (miss)        otherwise: binary64.
+ *        u >= m2  =>  lo <= hi (hit)        u <= -m2  =>  lo > hi (miss)        otherwise (|u| < m2 or unordered): binary64.
  * The undecided share is ~4 m2 / (hi - lo spread) ~ 1e-5 per test, scale-free because mag is the node's own. */
+#ifndef PT_SWZ_NEAR
+#define PT_SWZ_NEAR 1 /* 1: the LDS image also carries, per direction octant, the child the walk descends into (64-byte nodes) */
+#endif
+#if PT_SWZ_NEAR
+/*   words 12..15 near[8], u16 each: for octant o the NEAR child of a branch (shape_tree.ml:209: lhs if bit `axis` of o is set,
+ *               else rhs), PT_SWZ_LEAF for a leaf.  With it a visit needs no axis extraction, no bit test and no child select:
+ *               next = hit an inner node ? near[o] : skip[o]. */
+#define PT_SWZ_NODE_BYTES 64
+#else
 #define PT_SWZ_NODE_BYTES 48
+#endif
+#define PT_SWZ_LEAF 0xfffeu
 #define PT_SWZ_END 0xffffu
 /* bytes of LDS a wave keeps for traversal stacks: LDS-resident scenes walk the threaded image (no per-lane stack) and
  * only the camera-ray packet walk keeps its shared (node, mask) stack there: 12 bytes per level, rounded to 16 */
@@ -321,6 +344,9 @@ struct PtSceneView {
   const uint32_t* skip32; /* threaded global walk: n_nodes x 8, 0xffffffff = none */
   const unsigned char* nodes32; /* 32-byte binary32 image of the nodes for the walk from HBM / L2 */
   const unsigned char* swz_nodes; /* LDS-resident scenes: the binary32 filter image, PT_SWZ_NODE_BYTES per node */
+  const unsigned char* top;       /* scenes walked from HBM / L2: the LDS copy of PtSceneDev.top_nodes if has_top (else never dereferenced:
+                                     no node reference carries PT_TOP_FLAG) */
+  bool has_top;
   const double* sph;
   const double* tri;
   const uint8_t* kind;
@@ -344,6 +370,13 @@ __device__ __forceinline__ uint32_t pt_stack_pop(const PtThreadTag*, int) { retu
 
 #ifndef PT_WALK_MIN
 #define PT_WALK_MIN 8
+#endif
+#ifndef PT_LEAF_PREFETCH
+#define PT_LEAF_PREFETCH 1 /* triangle-only scenes walked from HBM / L2: request triangle k + 1 before testing triangle k */
+#endif
+#ifndef PT_WALK_LOOP
+#define PT_WALK_LOOP 0 /* 0: wave-level loop with a `want` ballot per turn; 1: the node walk as one divergent loop (fewer scalar
+                          instructions per turn, but the kernel is bound by VECTOR issue: measured 3 % slower) */
 #endif
 /* PT_DIAG (diagnostic builds only, tools/diag_utilisation.sh): re-purposes the COUNT counters of SECONDARY launches
  * to measure lane utilisation per traversal phase: nodes = useful lane steps, floor = lane slots the wave spent.
@@ -376,12 +409,17 @@ struct PtTraverser {
   PtTraceResult r;
   int sp;
   uint32_t node;
-  bool walking;
+  uint32_t walking; /* 0 / 1: an integer, so that "wants a node step" is ONE unsigned comparison (walking > leaf_n) */
   int leaf_first, leaf_n;
-  __device__ __forceinline__ bool wants_node() const { return walking && leaf_n == 0; }
+  __device__ __forceinline__ bool wants_node() const { return walking > (uint32_t)leaf_n; }
+  /* the same as a wave mask, straight from the comparison (a ballot of a boolean that is also branched on costs two more
+   * vector instructions per turn, and the walk is bound by vector issue); 34 = unsigned greater than, 38 = signed greater than */
+  __device__ __forceinline__ unsigned long long wants_node_mask() const { return __builtin_amdgcn_uicmp(walking, (uint32_t)leaf_n, 34); }
+  __device__ __forceinline__ unsigned long long holds_leaf_mask() const { return __builtin_amdgcn_sicmp(leaf_n, 0, 38); }
+  __device__ __forceinline__ unsigned long long walking_mask() const { return __builtin_amdgcn_uicmp(walking, 0u, 33); }
   __device__ __forceinline__ bool idle() const { return !walking && leaf_n == 0; }
   __device__ __forceinline__ void park() {
-    walking = false;
+    walking = 0u;
     leaf_n = 0;
   }
 
@@ -404,13 +442,17 @@ struct PtTraverser {
        * scale.  And max|1/d| is kept far above the binary32 subnormals (>= 2^-60): components of inv32 / (o inv)32 that
        * are subnormal -- or flushed to zero, whatever the f32 denormal mode of the code object -- are then wrong by
        * < 2^-126 (mag + |o|) absolute, which m2 >= 2^-19 (mag + |o|) 2^-60 + 1e-30 covers with room to spare. */
-      if (!(((double)sc.root_mag + omax) * imax < 0x1p100) || !(imax > 0x1p-60)) exact_slab = true;
+      const float fimax = (float)imax, fomax = (float)omax; /* (a magnitude beyond binary32 becomes +inf and fails the guard) */
+      if (!((sc.root_mag + fomax) * fimax < 0x1p100f) || !(fimax > 0x1p-60f)) exact_slab = true;
       fix = (float)inv.x; fiy = (float)inv.y; fiz = (float)inv.z;
       fnx = ORIGIN_ZERO ? 0.0f : -(float)(o.x * inv.x);
       fny = ORIGIN_ZERO ? 0.0f : -(float)(o.y * inv.y);
       fnz = ORIGIN_ZERO ? 0.0f : -(float)(o.z * inv.z);
-      k2 = (float)imax * 0x1.000002p-19f;
-      c2base = __builtin_fmaf((float)omax * 1.000001f, k2, 1e-30f);
+      k2 = fimax * 0x1.000002p-19f;
+      c2base = __builtin_fmaf(fomax * 1.000001f, k2, 1e-30f);
+      /* exact_slab folded into the margin: with m2 = NaN neither `u >= m2` nor `u < -m2` holds, so every test of such a ray
+       * is undecided and takes the binary64 code -- no per-visit instruction for the flag itself */
+      if (exact_slab) c2base = __builtin_nanf("");
     }
     r.t = PT_MAX_FINITE;
     r.slot = -1;
@@ -440,7 +482,7 @@ struct PtTraverser {
       one_over_a = 1.0 / qa;
     }
     sp = 0;
-    node = 0;
+    node = (G32 && sv.has_top) ? PT_TOP_FLAG : 0u; /* the root: slot 0 of the top image */
     walking = sc.n_nodes > 0;
     leaf_first = 0;
     leaf_n = 0;
@@ -471,9 +513,15 @@ struct PtTraverser {
         n_real = w1.z >> 16; /* meaningful for leaves only */
         mag = __uint_as_float(w1.w);
       } else { /* nd is the node's index; 32-byte global image: six binary32 bounds, a, b (leaf b: count | real << 15 | tag) */
-        const uint4* p = (const uint4*)(sv.nodes32 + (size_t)nd * 32u);
-        w0 = p[0];
-        w1 = p[1];
+        if (nd & PT_TOP_FLAG) { /* ... or PT_TOP_FLAG | byte offset into the LDS copy of the tree's top: same words */
+          const uint4* p = (const uint4*)(sv.top + (nd & (PT_TOP_FLAG - 1u)));
+          w0 = p[0];
+          w1 = p[1];
+        } else {
+          const uint4* p = (const uint4*)(sv.nodes32 + (size_t)nd * 32u);
+          w0 = p[0];
+          w1 = p[1];
+        }
         na = w1.z;
         const bool leaf = (w1.w >> 30) == PT_NODE_LEAF_AXIS;
         n_real = (w1.w >> 15) & 0x7fffu;
@@ -491,14 +539,21 @@ struct PtTraverser {
       const float u = __builtin_fminf(b, t32) - __builtin_fmaxf(a, 0.0f);
       const float m2 = __builtin_fmaf(mag, k2, c2);
       hit = u >= m2;
-      const bool undecided = active && (exact_slab || !(hit || u < -m2));
-      if (__builtin_amdgcn_ballot_w64(undecided) != 0) {
+      /* (a ray the filter does not apply to carries m2 = NaN: neither comparison holds, every test of it is undecided) */
+      /* one comparison, so that the ballot below is that comparison's own mask (a boolean assembled from two costs two more
+       * vector instructions per visit): |u| < m2 or unordered.  u == -m2 exactly now counts as a decided miss: it is one,
+       * m2 is twice the error bound */
+      /* (the wave mask straight from the comparison -- predicate 12 = unordered or less than; a ballot of the boolean that the
+       * branch below also uses makes the compiler materialise it per lane first) */
+      if (__builtin_amdgcn_fcmpf(__builtin_fabsf(u), active ? m2 : 0.0f, 12) != 0) {
+        const bool undecided = active && !(__builtin_fabsf(u) >= m2);
         if (COUNT) {
           if (undecided) n_undecided++;
           if (pt_lane() == __ffsll((long long)__ballot(1)) - 1) n_wave_fallbacks++;
         }
         if (undecided) { /* the reference's arithmetic, on the binary64 node (global memory: L2-resident, rarely read) */
-          const PtNode* np = sv.nodes + (SWZ ? nd / PT_SWZ_NODE_BYTES : nd);
+          const PtNode* np = sv.nodes + (SWZ ? nd / PT_SWZ_NODE_BYTES
+                                             : ((nd & PT_TOP_FLAG) ? *(const uint32_t*)(sv.top + (nd & (PT_TOP_FLAG - 1u)) + 48) : nd));
           /* 1 / d again (the same three divisions as Ray.create): opaque to the optimiser, or it hoists them out of the
            * walk and keeps six more registers live across the hot loop for a path taken in 1.6 % of the wave-steps */
           double qx = d.x, qy = d.y, qz = d.z;
@@ -526,8 +581,30 @@ struct PtTraverser {
     uint32_t na, nb, n_real;
     /* threaded image: where to go once this subtree is done (issued beside the node's own reads) */
     constexpr bool THREAD32 = !SWZ && std::is_same<StackT, PtThreadTag>::value;
-    const uint32_t skip = SWZ ? (uint32_t)*(const uint16_t*)(sv.swz_nodes + node + skip_off)
-                              : (THREAD32 ? sv.skip32[(size_t)node * 8u + dirs] : 0u);
+    uint32_t skip;
+    if (SWZ) skip = (uint32_t)*(const uint16_t*)(sv.swz_nodes + node + skip_off);
+    else if (!THREAD32) skip = 0u;
+    else if (node & PT_TOP_FLAG) { /* top image: 16-bit byte offsets, a top node's successor is a top node */
+      const uint32_t s16 = (uint32_t)*(const uint16_t*)(sv.top + (node & (PT_TOP_FLAG - 1u)) + 32u + 2u * dirs);
+      skip = s16 == 0xffffu ? 0xffffffffu : (PT_TOP_FLAG | s16);
+    } else skip = sv.skip32[(size_t)node * 8u + dirs];
+#if PT_SWZ_NEAR
+    if (SWZ) {
+      const uint32_t near_c = (uint32_t)*(const uint16_t*)(sv.swz_nodes + node + skip_off + 16u);
+      const bool hit = test_box(sv, node, na, nb, n_real);
+      const bool leaf_hit = hit && near_c == PT_SWZ_LEAF;
+      if (leaf_hit) {
+        leaf_first = (int)na;
+        leaf_n = (int)n_real; /* real slots; the NaN padding (main.ml:185) can never be selected */
+        if (COUNT && PT_DIAG == 0) c_prims += (unsigned long long)(MODE == PT_MODE_SIMD ? ((n_real + 3u) & ~3u) : n_real);
+      }
+      /* an inner node that was hit: its near child; else (miss, or a leaf taken) what follows this subtree */
+      const uint32_t nx = (hit && !leaf_hit) ? near_c : skip;
+      if (nx == PT_SWZ_END) walking = false;
+      else node = nx;
+      return;
+    }
+#endif
     const bool hit = test_box(sv, node, na, nb, n_real);
     if (hit) {
       const uint32_t axis = nb >> 30;
@@ -562,6 +639,83 @@ struct PtTraverser {
         --sp;
         node = PT_STACK_POP(stack, sp);
       }
+    }
+  }
+
+  /* ---- the same visit in two halves, for the walk from HBM / L2 with TWO rays per lane (pt_trace_ray2): the loads of
+   * both rays' nodes are issued before either is waited for, so a lane keeps two node -> child chains in flight. */
+  struct NodeWords {
+    uint4 w0, w1;
+    uint32_t skip;
+  };
+  __device__ __forceinline__ NodeWords load_node(const PtSceneView& sv, uint32_t nd) const {
+    static_assert(!SWZ, "the two-ray walk reads the 32-byte global image");
+    NodeWords w;
+    if (nd & PT_TOP_FLAG) {
+      const unsigned char* b = sv.top + (nd & (PT_TOP_FLAG - 1u));
+      w.w0 = ((const uint4*)b)[0];
+      w.w1 = ((const uint4*)b)[1];
+      const uint32_t s16 = (uint32_t)*(const uint16_t*)(b + 32u + 2u * dirs);
+      w.skip = s16 == 0xffffu ? 0xffffffffu : (PT_TOP_FLAG | s16);
+    } else {
+      const uint4* p = (const uint4*)(sv.nodes32 + (size_t)nd * 32u);
+      w.w0 = p[0];
+      w.w1 = p[1];
+      w.skip = sv.skip32[(size_t)nd * 8u + dirs];
+    }
+    return w;
+  }
+  /* node_step's arithmetic on words that have arrived (G32 branch of test_box + the descend / leaf / skip decision) */
+  __device__ __forceinline__ void finish_node(const PtSceneView& sv, const NodeWords& w, unsigned long long& c_nodes,
+                                              unsigned long long& c_prims) {
+    if (COUNT) c_nodes++;
+    const uint4 w0 = w.w0, w1 = w.w1;
+    const uint32_t na = w1.z;
+    const bool leaf = (w1.w >> 30) == PT_NODE_LEAF_AXIS;
+    const uint32_t n_real = (w1.w >> 15) & 0x7fffu;
+    const uint32_t nb = leaf ? ((w1.w & 0x7fffu) | (PT_NODE_LEAF_AXIS << 30)) : w1.w;
+    const float mag = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(__uint_as_float(w0.x)), __builtin_fabsf(__uint_as_float(w0.y))),
+                                                      __builtin_fmaxf(__builtin_fabsf(__uint_as_float(w0.z)), __builtin_fabsf(__uint_as_float(w0.w)))),
+                                      __builtin_fmaxf(__builtin_fabsf(__uint_as_float(w1.x)), __builtin_fabsf(__uint_as_float(w1.y)))) * 1.000001f;
+    const float t0x = __builtin_fmaf(__uint_as_float(w0.x), fix, fnx), t1x = __builtin_fmaf(__uint_as_float(w0.w), fix, fnx);
+    const float t0y = __builtin_fmaf(__uint_as_float(w0.y), fiy, fny), t1y = __builtin_fmaf(__uint_as_float(w1.x), fiy, fny);
+    const float t0z = __builtin_fmaf(__uint_as_float(w0.z), fiz, fnz), t1z = __builtin_fmaf(__uint_as_float(w1.y), fiz, fnz);
+    const float a = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(t0x, t1x), __builtin_fminf(t0y, t1y)), __builtin_fminf(t0z, t1z));
+    const float b = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(t0x, t1x), __builtin_fmaxf(t0y, t1y)), __builtin_fmaxf(t0z, t1z));
+    const float u = __builtin_fminf(b, t32) - __builtin_fmaxf(a, 0.0f);
+    const float m2 = __builtin_fmaf(mag, k2, c2);
+    bool hit = u >= m2;
+    const bool undecided = !(__builtin_fabsf(u) >= m2); /* as in test_box; exact_slab rays carry m2 = NaN */
+    if (__builtin_amdgcn_ballot_w64(undecided) != 0) {
+      if (COUNT) {
+        if (undecided) n_undecided++;
+        if (pt_lane() == __ffsll((long long)__ballot(1)) - 1) n_wave_fallbacks++;
+      }
+      if (undecided) { /* the reference's arithmetic on the binary64 node, as in test_box */
+        const PtNode* np = sv.nodes + ((node & PT_TOP_FLAG) ? *(const uint32_t*)(sv.top + (node & (PT_TOP_FLAG - 1u)) + 48) : node);
+        double qx = d.x, qy = d.y, qz = d.z;
+        asm volatile("" : "+v"(qx), "+v"(qy), "+v"(qz));
+        const V3 inv64 = v3(1.0 / qx, 1.0 / qy, 1.0 / qz);
+        hit = (!(pt_isfinite(inv64.x) && pt_isfinite(inv64.y) && pt_isfinite(inv64.z)))
+                  ? pt_slab_hit_exact(np->mn, o, inv64, 0.0, r.t)
+                  : pt_slab_hit_fast<ORIGIN_ZERO>(np->mn, o, inv64, 0.0, r.t);
+      }
+    }
+    bool descend = false;
+    if (hit) {
+      if (leaf) {
+        leaf_first = (int)na;
+        leaf_n = (int)n_real;
+        if (COUNT) c_prims += (unsigned long long)(nb & 0x3fffffffu);
+      } else {
+        const uint32_t axis = nb >> 30;
+        node = ((dirs >> axis) & 1u) ? na : (nb & 0x3fffffffu); /* near child first (shape_tree.ml:209) */
+        descend = true;
+      }
+    }
+    if (!descend) {
+      if (w.skip == 0xffffffffu) walking = false;
+      else node = w.skip;
     }
   }
 
@@ -666,6 +820,31 @@ struct PtTraverser {
 #endif
     } else {
       /* Array_leaf.intersect, shape_tree.ml:299-311: shrinking t_max, later element wins ties */
+#if PT_LEAF_PREFETCH
+      if (!SWZ && sv.kind == nullptr) {
+        /* a triangle-only scene walked from HBM / L2 (a mesh): the leaf's triangles are 80-byte records that mostly miss
+         * every cache level above L2, and testing them one after the other made a leaf visit a chain of up to
+         * length_cutoff dependent round trips -- the longest waits of the whole walk.  The next triangle's nine
+         * coordinates are requested before the current one is tested; same tests, same order. */
+        const double* tv = sv.tri + (size_t)leaf_first * 10;
+        V3 a = pt_load_v3(tv), b = pt_load_v3(tv + 3), c = pt_load_v3(tv + 6);
+        for (int k = 0; k < leaf_n; ++k) {
+          const double* nx = sv.tri + (size_t)(leaf_first + (k + 1 < leaf_n ? k + 1 : k)) * 10;
+          const V3 na = pt_load_v3(nx), nb = pt_load_v3(nx + 3), nc = pt_load_v3(nx + 6);
+          double t, u, v;
+          if (pt_triangle_intersect(a, b, c, o, d, t_min, r.t, &t, &u, &v)) {
+            r.t = t;
+            r.u = u;
+            r.v = v;
+            r.slot = leaf_first + k;
+          }
+          a = na; b = nb; c = nc;
+        }
+        leaf_n = 0;
+        if (FILT) update_t32();
+        return;
+      }
+#endif
       for (int k = 0; k < leaf_n; ++k) {
         if (COUNT && PT_DIAG == 3 && !ORIGIN_ZERO) {
           c_nodes++;
@@ -735,21 +914,37 @@ __device__ __forceinline__ PtTraceResult pt_trace_ray(const PtSceneDev& sc, cons
     if (tr.FILT) tr.update_t32(); /* the filter's copy of t: stale, it would pass boxes beyond the restored hit */
   }
   while (valid && (tr.walking || tr.leaf_n > 0)) {
+#if PT_WALK_LOOP
+    /* The node walk as ONE divergent loop: a lane stays in it while it wants node steps, so the lanes still walking are
+     * simply the loop's exec mask (no per-turn ballot of a `want` flag, no `continue`, no exit-reason bookkeeping: the
+     * first version of this loop spent ~19 of its ~80 instructions per turn on that).  Same rule as before: once fewer than
+     * PT_WALK_MIN lanes are walking and some lane holds a leaf, the pending packets are intersected first. */
+    if (tr.wants_node()) {
+      bool leaf_waiting = false; /* wave-uniform: a lane of this wave left the walk holding a leaf */
+      for (;;) {
+        if (COUNT && PT_DIAG == 1 && !ORIGIN_ZERO) PT_DIAG_WAVE_SLOTS(c_floor);
+        tr.node_step(sv, stack, c_nodes, c_prims);
+        if (__ballot(tr.leaf_n > 0) != 0) leaf_waiting = true;
+        if (!tr.wants_node()) break;
+        if (leaf_waiting && (int)__popcll(__ballot(1)) < PT_WALK_MIN) break;
+      }
+    }
+#else
     for (;;) {
       /* keep walking while enough lanes still want a node step; once fewer than PT_WALK_MIN do and some lane
        * already holds a leaf, intersect the pending packets first (the stragglers resume afterwards) */
-      const bool want = tr.wants_node();
-      const unsigned long long wm = __ballot(want);
+      const unsigned long long wm = tr.wants_node_mask();
       if (wm == 0) break;
-      if ((int)__popcll(wm) < PT_WALK_MIN && __ballot(tr.leaf_n > 0) != 0) break;
+      if (pt_popc_mask(wm) < PT_WALK_MIN && tr.holds_leaf_mask() != 0) break;
       if (COUNT && PT_DIAG == 1 && !ORIGIN_ZERO) PT_DIAG_WAVE_SLOTS(c_floor);
-      if (!want) continue;
+      if (!tr.wants_node()) continue;
       tr.node_step(sv, stack, c_nodes, c_prims);
     }
+#endif
     if (tr.leaf_n > 0) tr.packet(sv, c_nodes, c_floor);
     /* nobody holds a leaf here: a safe place to stop.  The ballot sees the rays that are still walking (finished
      * lanes have left the loop), and every one of them sees the same count. */
-    if (tc && (int)__popcll(__ballot(tr.walking)) < tc->min_active) break;
+    if (tc && pt_popc_mask(tr.walking_mask()) < tc->min_active) break;
   }
   if (tc) {
     tc->unfinished = valid && tr.walking;
@@ -760,6 +955,70 @@ __device__ __forceinline__ PtTraceResult pt_trace_ray(const PtSceneDev& sc, cons
     c_filter[1] += tr.n_wave_fallbacks;
   }
   return tr.r;
+}
+
+/* Scene.intersect for TWO rays held by this lane (A and B), walked from HBM / L2 over the threaded 32-byte image.
+ * Large scenes (ganesha-like: 92 k nodes) walk from L2 / Infinity Cache and wait for the chain node -> child: with one ray
+ * per lane a wave spent 64 % of its life parked on s_waitcnt with the vector pipe half busy (profiles/r02_ganesha_sq.json),
+ * and more waves per SIMD are not to be had (the triangle test needs ~100 VGPRs).  Two rays per lane double the chains in
+ * flight at the same occupancy: both rays' node words are requested before either is tested.  Each ray still performs exactly
+ * pt_trace_ray's own sequence of box and leaf tests (its state is its own traverser), so hits, t and the work counters are
+ * unchanged.  Leaves are tested one ray at a time (the triangle code is what the registers are sized for).
+ * Tail cut as in pt_trace_ray: the pair of chunks stops once fewer than `min_active` of its <= 128 rays are still walking. */
+#ifndef PT_DUAL_WALK_MIN
+#define PT_DUAL_WALK_MIN 12
+#endif
+template <int MODE, bool COUNT, bool ORIGIN_ZERO>
+__device__ __forceinline__ void pt_trace_ray2(const PtSceneDev& sc, const PtSceneView& sv, V3 oA, V3 dA, V3 oB, V3 dB, bool validA,
+                                              bool validB, PtTailCtl& tcA, PtTailCtl& tcB, int min_active, PtTraceResult& rA,
+                                              PtTraceResult& rB, unsigned long long& c_nodes, unsigned long long& c_prims,
+                                              unsigned long long& c_floor, unsigned long long* c_filter) {
+  typedef PtTraverser<MODE, COUNT, ORIGIN_ZERO, PtThreadTag, false> Tr;
+  Tr A, B;
+  unsigned long long no_count = 0;
+  A.begin(sc, sv, oA, dA, (validA && !tcA.resume) ? c_floor : no_count);
+  B.begin(sc, sv, oB, dB, (validB && !tcB.resume) ? c_floor : no_count);
+  if (tcA.resume) {
+    A.node = tcA.node; A.r.t = tcA.t; A.r.u = tcA.u; A.r.v = tcA.v; A.r.slot = tcA.slot;
+    A.update_t32();
+  }
+  if (tcB.resume) {
+    B.node = tcB.node; B.r.t = tcB.t; B.r.u = tcB.u; B.r.v = tcB.v; B.r.slot = tcB.slot;
+    B.update_t32();
+  }
+  if (!validA) A.park();
+  if (!validB) B.park();
+  for (;;) {
+    if (__ballot(A.walking || A.leaf_n > 0 || B.walking || B.leaf_n > 0) == 0) break;
+    for (;;) {
+      const bool wantA = A.wants_node(), wantB = B.wants_node();
+      const unsigned long long wa = __ballot(wantA), wb = __ballot(wantB);
+      if ((wa | wb) == 0) break;
+      if ((int)(__popcll(wa) + __popcll(wb)) < PT_DUAL_WALK_MIN && __ballot(A.leaf_n > 0 || B.leaf_n > 0) != 0) break;
+      /* both requests go out before either answer is looked at; only the lanes that want a step ask (the texture-address
+       * unit works per active lane: unconditional loads for all 64 lanes more than doubled its load at 0.4 lane utilisation) */
+      typename Tr::NodeWords wA, wB;
+      wA.w0 = wA.w1 = wB.w0 = wB.w1 = make_uint4(0, 0, 0, 0);
+      wA.skip = wB.skip = 0u;
+      if (wantA) wA = A.load_node(sv, A.node);
+      if (wantB) wB = B.load_node(sv, B.node);
+      if (wantA) A.finish_node(sv, wA, c_nodes, c_prims);
+      if (wantB) B.finish_node(sv, wB, c_nodes, c_prims);
+    }
+    if (A.leaf_n > 0) A.packet(sv, c_nodes, c_floor);
+    if (B.leaf_n > 0) B.packet(sv, c_nodes, c_floor);
+    if (min_active > 0 && (int)(__popcll(__ballot(A.walking)) + __popcll(__ballot(B.walking))) < min_active) break;
+  }
+  tcA.unfinished = validA && A.walking;
+  tcA.node = A.node;
+  tcB.unfinished = validB && B.walking;
+  tcB.node = B.node;
+  if (COUNT && c_filter) {
+    c_filter[0] += A.n_undecided + B.n_undecided;
+    c_filter[1] += A.n_wave_fallbacks + B.n_wave_fallbacks;
+  }
+  rA = A.r;
+  rB = B.r;
 }
 
 /* Camera rays: the 64 rays of a wave are one 8x8 pixel tile of one pass, so they walk the tree TOGETHER -- one
@@ -890,16 +1149,28 @@ __device__ __forceinline__ PtTraceResult pt_trace_packet(const PtSceneDev& sc, c
 /* Where this workgroup traverses from.  LDS_SCENE: the whole tree and every leaf packet are first copied into LDS
  * behind the traversal stacks (nodes expanded to the swizzled image on the way); ends with a __syncthreads(). */
 template <int MODE, bool LDS_SCENE, typename StackT>
-__device__ __forceinline__ PtSceneView pt_scene_view(const PtSceneDev& sc, unsigned char* lds_raw, int stack_depth) {
+__device__ __forceinline__ PtSceneView pt_scene_view(const PtSceneDev& sc, unsigned char* lds_raw, int stack_depth, bool want_top = false) {
   const uint32_t waves_per_block = blockDim.x >> 6;
   PtSceneView sv;
   sv.nodes = sc.nodes;
   sv.skip32 = sc.node_skip32;
   sv.nodes32 = (const unsigned char*)sc.nodes32;
   sv.swz_nodes = nullptr;
+  sv.top = lds_raw;
+  sv.has_top = false;
+  if (!LDS_SCENE && want_top && sc.n_top > 0) { /* the tree's top into LDS (the caller's barrier follows) */
+    const uint4* src = (const uint4*)sc.top_nodes;
+    uint4* dst = (uint4*)lds_raw;
+    for (int k = threadIdx.x; k < sc.n_top * (PT_TOP_NODE_BYTES / 16); k += blockDim.x) dst[k] = src[k];
+    sv.has_top = true;
+    sv.skip32 = sc.node_skip32_top;
+  }
   sv.sph = sc.sph;
   sv.tri = sc.tri;
   sv.kind = sc.slot_kind;
+#if PT_LEAF_PREFETCH
+  if (!LDS_SCENE && sc.all_triangles) sv.kind = nullptr; /* PtTraverser::packet: the pipelined triangle loop */
+#endif
   if (LDS_SCENE) {
     size_t off = ((size_t)waves_per_block * PT_WAVE_STACK_BYTES(LDS_SCENE, StackT, stack_depth) + 63) & ~(size_t)63;
     unsigned char* l_nodes = lds_raw + off;
@@ -931,6 +1202,9 @@ __device__ __forceinline__ PtSceneView pt_scene_view(const PtSceneDev& sc, unsig
       for (int o = 0; o < 8; ++o) {
         const uint32_t nx = sc.node_skip[(size_t)k * 8 + o];
         sk[o] = nx == 0xffffu ? (uint16_t)PT_SWZ_END : (uint16_t)(nx * PT_SWZ_NODE_BYTES);
+#if PT_SWZ_NEAR
+        sk[8 + o] = leaf ? (uint16_t)PT_SWZ_LEAF : (uint16_t)((((o >> axis) & 1) ? src->a : (src->b & 0x3fffffffu)) * PT_SWZ_NODE_BYTES);
+#endif
       }
     }
     {
@@ -1039,6 +1313,10 @@ struct PtChunkFeed {
 #ifndef PT_TAIL_CUT
 #define PT_TAIL_CUT 16 /* 0 = off */
 #endif
+#ifndef PT_TRACE_DUAL
+#define PT_TRACE_DUAL 0 /* scenes walked from HBM / L2: 1 = two rays per lane (pt_trace_ray2), 0 = one */
+#endif
+#define PT_DUAL_SUSP_CAP 128 /* parked walks a wave of the two-ray kernel can hold */
 #ifndef PT_TRACE_BLOCK_LDS
 #define PT_TRACE_BLOCK_LDS 1024 /* workgroup size when the scene is copied to LDS (one copy per workgroup) */
 #endif
@@ -1059,7 +1337,7 @@ template <int MODE, bool COUNT, bool PRIMARY, bool LDS_SCENE, bool PACKET>
  * writes per launch on cornell). */
 __global__ __launch_bounds__(PT_TRACE_BLOCK_OF(MODE, LDS_SCENE), (LDS_SCENE && MODE == PT_MODE_SIMD) ? PT_TRACE_LDS_WAVES : PT_TRACE_GLOBAL_WAVES) void k_trace(PtSceneDev sc, PtQueue q, PtHits hits, int stack_depth,
                                                PtCounters* counters, PtGenParams g, const double* __restrict__ alpha,
-                                               uint32_t n_primary, uint32_t* work, uint4* susp) {
+                                               uint32_t n_primary, uint32_t* work, uint4* susp, int top_in_lds) {
   extern __shared__ __attribute__((aligned(64))) unsigned char lds_raw[];
   const int lane = pt_lane();
   const int wave_in_block = (int)(threadIdx.x >> 6);
@@ -1068,8 +1346,8 @@ __global__ __launch_bounds__(PT_TRACE_BLOCK_OF(MODE, LDS_SCENE), (LDS_SCENE && M
   StackT* stack = (StackT*)(lds_raw + (size_t)wave_in_block * PT_WAVE_STACK_BYTES(LDS_SCENE, StackT, stack_depth));
   __shared__ uint32_t lds_chunk_ctr;
   if (threadIdx.x == 0) lds_chunk_ctr = 0u;
-  const PtSceneView sv = pt_scene_view<MODE, LDS_SCENE, StackT>(sc, lds_raw, stack_depth);
-  if (!LDS_SCENE) __syncthreads(); /* pt_scene_view ends with a barrier only when it copies the scene */
+  const PtSceneView sv = pt_scene_view<MODE, LDS_SCENE, StackT>(sc, lds_raw, stack_depth, top_in_lds != 0);
+  if (!LDS_SCENE) __syncthreads(); /* pt_scene_view ends with a barrier only when it copies the whole scene */
   const uint32_t n = PRIMARY ? n_primary : *q.count;
   PtChunkFeed feed;
   feed.init(work, (uint32_t)(((unsigned long long)n + PT_WAVE - 1) / PT_WAVE), &lds_chunk_ctr);
@@ -1101,11 +1379,102 @@ __global__ __launch_bounds__(PT_TRACE_BLOCK_OF(MODE, LDS_SCENE), (LDS_SCENE && M
       if (COUNT && valid) c_seg++;
       const PtTraceResult r = pt_trace_packet<MODE, COUNT, PRIMARY, LDS_SCENE>(sc, sv, wstack, valid, o, d, c_nodes, c_prims, c_floor, c_filter);
       if (valid) {
-        hits.t[i] = r.t;
-        hits.slot[i] = r.slot;
-        if (MODE == PT_MODE_ARRAY && sc.has_triangles) {
-          hits.u[i] = r.u;
-          hits.v[i] = r.v;
+        pt_hit_store(hits, i, r.t, r.slot, r.u, r.v, MODE == PT_MODE_ARRAY && sc.has_triangles);
+      }
+    }
+  } else if constexpr (!LDS_SCENE && PT_TRACE_DUAL != 0 && PT_DIAG == 0) {
+    /* TWO rays per lane (pt_trace_ray2): the wave takes two chunks at a time -- fresh ones from the feed, or 64 parked
+     * walks from its own list.  Tail cut on the pair: it stops once fewer than 2 x PT_TAIL_CUT of its <= 128 rays are
+     * still walking; at most 2 x PT_TAIL_CUT - 1 states are parked per turn, 64 are taken back as soon as 64 have gathered,
+     * so the list never holds more than 63 + 31 (PT_DUAL_SUSP_CAP = 128 per wave, three 16-byte words per state). */
+    constexpr bool TAIL_UV = MODE == PT_MODE_ARRAY;
+    uint4* my_susp = susp + ((size_t)blockIdx.x * (blockDim.x >> 6) + wave_in_block) * (PT_DUAL_SUSP_CAP * 3);
+    uint32_t n_susp = 0; /* wave-uniform */
+    bool more = true;
+    for (;;) {
+      bool got[2], resume[2], valid[2];
+      uint32_t idx[2];
+      uint4 parked[2], parked_uv[2], parked_w[2];
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        got[k] = resume[k] = valid[k] = false;
+        idx[k] = 0;
+        parked[k] = parked_uv[k] = parked_w[k] = make_uint4(0, 0, 0, 0);
+        if (n_susp >= (uint32_t)PT_WAVE || (!more && n_susp > 0)) {
+          const uint32_t take = n_susp < (uint32_t)PT_WAVE ? n_susp : (uint32_t)PT_WAVE, base = n_susp - take;
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); /* this wave's own parked states, written below */
+          got[k] = resume[k] = true;
+          valid[k] = (uint32_t)lane < take;
+          if (valid[k]) {
+            parked[k] = my_susp[base + lane];
+            parked_w[k] = my_susp[2 * PT_DUAL_SUSP_CAP + base + lane];
+            if (TAIL_UV) parked_uv[k] = my_susp[PT_DUAL_SUSP_CAP + base + lane];
+          }
+          idx[k] = parked[k].x;
+          n_susp = base;
+        } else if (more) {
+          more = feed.take(chunk);
+          if (more) {
+            got[k] = true;
+            idx[k] = chunk * PT_WAVE + lane;
+            valid[k] = idx[k] < n;
+          }
+        }
+      }
+      if (!got[0] && !got[1]) break;
+      V3 o[2], d[2];
+      PtTailCtl tc[2];
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        o[k] = v3(0.0, 0.0, 0.0);
+        d[k] = v3(0.0, 0.0, -1.0); /* P3.origin */
+        if (valid[k]) {
+          if (PRIMARY) {
+            const PtPrimarySample ps = pt_primary_decode(g, idx[k]);
+            valid[k] = ps.valid;
+            if (valid[k]) d[k] = pt_primary_dir(sc, g, ps, alpha);
+          } else {
+            pt_q_load_ray(q, idx[k], o[k], d[k]);
+            if (pt_is_hole(d[k].x)) { /* never parked, so never seen on resume */
+              valid[k] = false;
+              hits.slot[idx[k]] = PT_SLOT_HOLE;
+              o[k] = v3(0.0, 0.0, 0.0);
+              d[k] = v3(0.0, 0.0, -1.0);
+            }
+          }
+        }
+        if (COUNT && valid[k] && !resume[k]) c_seg++;
+        tc[k].min_active = 0;
+        tc[k].resume = resume[k] && valid[k];
+        tc[k].node = parked_w[k].x;
+        tc[k].slot = (int)parked_w[k].y;
+        tc[k].t = __hiloint2double((int)parked[k].w, (int)parked[k].z);
+        tc[k].u = __hiloint2double((int)parked_uv[k].y, (int)parked_uv[k].x);
+        tc[k].v = __hiloint2double((int)parked_uv[k].w, (int)parked_uv[k].z);
+        tc[k].unfinished = false;
+      }
+      PtTraceResult r[2];
+      /* the last chunks of a wave run to completion */
+      pt_trace_ray2<MODE, COUNT, PRIMARY>(sc, sv, o[0], d[0], o[1], d[1], valid[0], valid[1], tc[0], tc[1], more ? 2 * PT_TAIL_CUT : 0, r[0],
+                                          r[1], c_nodes, c_prims, c_floor, c_filter);
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const bool park = tc[k].unfinished;
+        if (valid[k] && !park) {
+          pt_hit_store(hits, idx[k], r[k].t, r[k].slot, r[k].u, r[k].v, MODE == PT_MODE_ARRAY && sc.has_triangles);
+        }
+        const unsigned long long pm = __ballot(park);
+        if (pm != 0) {
+          if (park) {
+            const uint32_t at = n_susp + (uint32_t)__popcll(pm & ((1ull << lane) - 1ull));
+            my_susp[at] = make_uint4(idx[k], 0u, (uint32_t)__double2loint(r[k].t), (uint32_t)__double2hiint(r[k].t));
+            my_susp[2 * PT_DUAL_SUSP_CAP + at] = make_uint4(tc[k].node, (uint32_t)r[k].slot, 0u, 0u);
+            if (TAIL_UV)
+              my_susp[PT_DUAL_SUSP_CAP + at] = make_uint4((uint32_t)__double2loint(r[k].u), (uint32_t)__double2hiint(r[k].u),
+                                                          (uint32_t)__double2loint(r[k].v), (uint32_t)__double2hiint(r[k].v));
+          }
+          n_susp += (uint32_t)__popcll(pm);
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         }
       }
     }
@@ -1180,12 +1549,7 @@ __global__ __launch_bounds__(PT_TRACE_BLOCK_OF(MODE, LDS_SCENE), (LDS_SCENE && M
       }
       const bool park = TAIL && tc.unfinished;
       if (valid && !park) {
-        hits.t[i] = r.t;
-        hits.slot[i] = r.slot;
-        if (MODE == PT_MODE_ARRAY && sc.has_triangles) {
-          hits.u[i] = r.u;
-          hits.v[i] = r.v;
-        }
+        pt_hit_store(hits, i, r.t, r.slot, r.u, r.v, MODE == PT_MODE_ARRAY && sc.has_triangles);
       }
       if (TAIL) {
         const unsigned long long pm = __ballot(park);
@@ -1268,12 +1632,7 @@ __global__ __launch_bounds__(PT_TRACE_BLOCK_OF(MODE, LDS_SCENE), PT_TRACE_GLOBAL
     if (im == ~0ull || (more && (int)__popcll(im) >= PT_REFILL_MIN)) {
       /* hand in the finished rays, take the next positions */
       if (idle && ray != 0xffffffffu) {
-        hits.t[ray] = tr.r.t;
-        hits.slot[ray] = tr.r.slot;
-        if (MODE == PT_MODE_ARRAY && sc.has_triangles) {
-          hits.u[ray] = tr.r.u;
-          hits.v[ray] = tr.r.v;
-        }
+        pt_hit_store(hits, ray, tr.r.t, tr.r.slot, tr.r.u, tr.r.v, MODE == PT_MODE_ARRAY && sc.has_triangles);
         ray = 0xffffffffu;
       }
       if (!more) break; /* every lane idle and nothing left */
@@ -1692,9 +2051,18 @@ __device__ __forceinline__ void pt_shade_entry(const PtSceneDev& sc, const PtQue
         /* None -> add_mul emit0 attn0 (background ray), integrator.ml:36 */
         result = v3_fma(attn0, pt_background(sc, d), emit0);
       } else {
-        const double t_hit = hits.t[i];
+        double t_hit, bu = 0.0, bv = 0.0;
+        if (sc.has_triangles) { /* one 32-byte record (PtHits) */
+          const double2* hp = (const double2*)(hits.tuv + i);
+          const double2 h0 = hp[0], h1 = hp[1];
+          t_hit = h0.x;
+          bu = h0.y;
+          bv = h1.x;
+        } else {
+          t_hit = hits.t[i];
+        }
         const bool is_tri = sc.has_triangles && sc.slot_kind[slot] != PT_SLOT_SPHERE;
-        const PtSurface sf = pt_surface_hit<CAT>(sc, o, d, slot, t_hit, is_tri ? hits.u[i] : 0.0, is_tri ? hits.v[i] : 0.0);
+        const PtSurface sf = pt_surface_hit<CAT>(sc, o, d, slot, t_hit, is_tri ? bu : 0.0, is_tri ? bv : 0.0);
         const PtShadeRec& m = *sf.m;
         const V3 point = sf.point;
         const Quat rot_inv = pt_quat_conj(sf.rot);
@@ -2078,22 +2446,26 @@ __global__ __launch_bounds__(PT_POOL_THREADS, PT_SHADE_WAVES) void k_shade_pool(
       int sl = -1;
       PtShadeOut so;
       so.keep = false;
-#pragma unroll
-      for (int k = 0; k < PT_N_SHADE_CAT; ++k) {
-        if (c == k) { /* wave-uniform */
-          cnt[k] = start;
-          if (live) {
-            const uint2 e = pool[k][start + lane];
-            i = e.x;
-            sl = (int)e.y;
-          }
-          if (k == PT_CAT_MISS) pt_shade_entry<EMIT, PRIMARY, PT_CAT_MISS>(sc, q, hits, contrib, alpha, bounce, last_bounce, g, i, live, so);
-          if (k == PT_CAT_LAMBERT_SOLID) pt_shade_entry<EMIT, PRIMARY, PT_CAT_LAMBERT_SOLID>(sc, q, hits, contrib, alpha, bounce, last_bounce, g, i, live, so, sl);
-          if (k == PT_CAT_LAMBERT_CHECKER) pt_shade_entry<EMIT, PRIMARY, PT_CAT_LAMBERT_CHECKER>(sc, q, hits, contrib, alpha, bounce, last_bounce, g, i, live, so, sl);
-          if (k == PT_CAT_METAL) pt_shade_entry<EMIT, PRIMARY, PT_CAT_METAL>(sc, q, hits, contrib, alpha, bounce, last_bounce, g, i, live, so, sl);
-          if (k == PT_CAT_DIELECTRIC) pt_shade_entry<EMIT, PRIMARY, PT_CAT_DIELECTRIC>(sc, q, hits, contrib, alpha, bounce, last_bounce, g, i, live, so, sl);
-        }
+      /* one category per step (wave-uniform `c`): each case reads its own list and runs its own specialisation */
+#define PT_POOL_STEP(K, ...)                                                                                               \
+  case K: {                                                                                                                \
+    cnt[K] = start;                                                                                                        \
+    if (live) {                                                                                                            \
+      const uint2 e = pool[K][start + lane];                                                                               \
+      i = e.x;                                                                                                             \
+      sl = (int)e.y;                                                                                                       \
+    }                                                                                                                      \
+    pt_shade_entry<EMIT, PRIMARY, K>(sc, q, hits, contrib, alpha, bounce, last_bounce, g, i, live, so, ##__VA_ARGS__);    \
+  } break;
+      switch (c) {
+        PT_POOL_STEP(PT_CAT_MISS)
+        PT_POOL_STEP(PT_CAT_LAMBERT_SOLID, sl)
+        PT_POOL_STEP(PT_CAT_LAMBERT_CHECKER, sl)
+        PT_POOL_STEP(PT_CAT_METAL, sl)
+        PT_POOL_STEP(PT_CAT_DIELECTRIC, sl)
+        default: break;
       }
+#undef PT_POOL_STEP
       PT_TM(tm_entry, tm_t);
       if (c != PT_CAT_MISS && !last_bounce) pt_pool_push<EMIT>(sc, out, so, lds_out);
       PT_TM(tm_push, tm_t);

@@ -310,43 +310,60 @@ PT_HD double pt_atan(double x) {
   return neg ? -r : r;
 }
 
+/* The constants of atan2's special cases (zeros, infinities, huge ratios) are only ever needed in branches that almost
+ * never run, but as plain literals the device compiler materialises all of them ahead of the shade kernel's main loop and
+ * keeps them in registers across it -- six 64-bit values the 128-VGPR kernel then spills.  Behind an empty volatile asm a
+ * value is made where it is used.  Same bits either way. */
+#define PT_LIT_PI 3.1415926535897931160E+00
+#define PT_LIT_PI_LO 1.2246467991473531772E-16
+#define PT_LIT_PI_O_2 1.5707963267948965580E+00
+#define PT_LIT_PI_O_4 7.8539816339744827900E-01
+#if defined(__HIP_DEVICE_COMPILE__)
+template <unsigned long long BITS>
+__device__ __forceinline__ double pt_rare_const() { /* the two v_mov of a 64-bit literal, pinned to the place of use */
+  unsigned lo, hi;
+  asm volatile("v_mov_b32 %0, %2\n\tv_mov_b32 %1, %3" : "=v"(lo), "=v"(hi) : "i"((unsigned)(BITS & 0xffffffffull)), "i"((unsigned)(BITS >> 32)));
+  return __hiloint2double((int)hi, (int)lo);
+}
+#define PT_RARE_CONST(x) pt_rare_const<__builtin_bit_cast(unsigned long long, (double)(x))>() /* x: a literal expression */
+#else
+#define PT_RARE_CONST(x) (x)
+#endif
 PT_HD double pt_atan2(double y, double x) {
-  const double pi = 3.1415926535897931160E+00;
-  const double pi_lo = 1.2246467991473531772E-16;
-  const double pi_o_2 = 1.5707963267948965580E+00;
-  const double pi_o_4 = 7.8539816339744827900E-01;
+  const double pi = PT_LIT_PI;
+  const double pi_lo = PT_LIT_PI_LO;
   if (x != x || y != y) return pt_nan();
   if (x == 1.0) return pt_atan(y);
   int m = pt_signbit(y) | (pt_signbit(x) << 1);
   if (y == 0.0) {
     if (m == 0 || m == 1) return y;
-    return (m == 2) ? pi : -pi;
+    return (m == 2) ? PT_RARE_CONST(PT_LIT_PI) : PT_RARE_CONST(-PT_LIT_PI);
   }
-  if (x == 0.0) return pt_signbit(y) ? -pi_o_2 : pi_o_2;
+  if (x == 0.0) return pt_signbit(y) ? PT_RARE_CONST(-PT_LIT_PI_O_2) : PT_RARE_CONST(PT_LIT_PI_O_2);
   int xinf = !pt_isfinite(x), yinf = !pt_isfinite(y);
   if (xinf) {
     if (yinf) {
       switch (m) {
-        case 0: return pi_o_4;
-        case 1: return -pi_o_4;
-        case 2: return 3.0 * pi_o_4;
-        default: return -3.0 * pi_o_4;
+        case 0: return PT_RARE_CONST(PT_LIT_PI_O_4);
+        case 1: return PT_RARE_CONST(-PT_LIT_PI_O_4);
+        case 2: return PT_RARE_CONST(3.0 * PT_LIT_PI_O_4);
+        default: return PT_RARE_CONST(-3.0 * PT_LIT_PI_O_4);
       }
     }
     switch (m) {
       case 0: return 0.0;
       case 1: return -0.0;
-      case 2: return pi;
-      default: return -pi;
+      case 2: return PT_RARE_CONST(PT_LIT_PI);
+      default: return PT_RARE_CONST(-PT_LIT_PI);
     }
   }
-  if (yinf) return pt_signbit(y) ? -pi_o_2 : pi_o_2;
+  if (yinf) return pt_signbit(y) ? PT_RARE_CONST(-PT_LIT_PI_O_2) : PT_RARE_CONST(PT_LIT_PI_O_2);
   int ey = (int)((pt_bits(y) >> 52) & 0x7ff);
   int ex = (int)((pt_bits(x) >> 52) & 0x7ff);
   int k = ey - ex;
   double z;
   if (k > 60)
-    z = pi_o_2 + 0.5 * pi_lo;
+    z = PT_RARE_CONST(PT_LIT_PI_O_2 + 0.5 * PT_LIT_PI_LO);
   else if ((m & 2) && k < -60)
     z = 0.0;
   else

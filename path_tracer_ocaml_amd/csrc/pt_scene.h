@@ -17,6 +17,8 @@
 #include <stdint.h>
 
 #define PT_NODE_LEAF_AXIS 3u /* axis code stored in the two top bits of `b` for leaves */
+#define PT_TOP_FLAG 0x20000000u /* a node reference into the LDS-resident top image (PtSceneDev.top_nodes): flag | byte offset */
+#define PT_TOP_NODE_BYTES 64
 #define PT_MAX_FINITE 1.7976931348623157e308
 
 /* One BVH node, 64 bytes.  Tree.t = Bbox.t * (Leaf | Branch {axis; lhs; rhs}), shape_tree.ml:153-161 */
@@ -106,6 +108,16 @@ struct PtSceneDev {
   /* n_nodes x 32 bytes: mn.xyz, mx.xyz rounded to binary32, a, b (leaf b: padded count | real count << 15 | tag): the filter
    * image of the walk from HBM / L2 -- half the bytes per visit of the 64-byte binary64 node, which only undecided tests read */
   const void* nodes32;
+  /* Scenes walked from HBM / L2: the TOP of the tree (the first n_top nodes in breadth-first order) as 64-byte records that
+   * every trace workgroup copies into LDS -- 6 binary32 bounds, links a / b as in nodes32, eight 16-bit skip links (byte
+   * offsets into this image; the node that follows a top node's subtree is an ancestor's sibling, hence a top node too), the
+   * node's own index.  A link to a top node is PT_TOP_FLAG | byte offset, here and in node_skip32_top (= node_skip32 with
+   * top targets encoded that way).  Half of a large mesh's node visits are within its first ~1000 nodes: those steps stop
+   * waiting for L2.  NULL / 0 when the scene has no such image. */
+  const uint32_t* top_nodes;
+  const uint32_t* node_skip32_top;
+  int32_t n_top;
+  int32_t all_triangles; /* 1: every tree slot is a triangle (a mesh): the leaf loop needs no per-slot kind */
   /* unit vector (camera space) along which the primitives' centres vary least = the normal of the scene's ground plane when it
    * has one.  A HEURISTIC sort key only (shade bins survivors by the elevation of the new direction above that plane, a
    * predictor of how long the next walk is); it never enters a pixel value. */

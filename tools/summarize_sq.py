@@ -6,8 +6,12 @@ usage: tools/summarize_sq.py gpurun_out/r02_shirley r02 shirley_1080p_spp64_d8
 
 Derived figures (MI355X_MICROARCH.md, "rocprofv3 PMC slots": SQ_*_CYCLES and SQ_ACTIVE_INST_* count quad-cycles;
 SQ_BUSY_CYCLES counts cycles once per shader engine, 32 of them):
-  cycles          = SQ_BUSY_CYCLES / 32                                kernel duration in shader cycles, summed over launches
+  cycles          = GRBM_GUI_ACTIVE of the kernel's dispatches (sq_c pass, scaled to the sq_a pass by SQ_WAVE_CYCLES): the
+                    kernel's duration in shader cycles, summed over launches.  SQ_BUSY_CYCLES / 32 (one count per shader
+                    engine) is kept as cycles_sq: it UNDER-counts the duration by >= 10 % on kernels that keep every engine
+                    busy (round 2 got valu_busy 1.115 from it and clamped); no figure below is clamped any more
   valu_busy       = 4 SQ_ACTIVE_INST_VALU / (1024 SIMDs x cycles)      share of SIMD time the vector pipe issues
+  valu_issue_from_insts = 4 SQ_INSTS_VALU / (1024 SIMDs x cycles)      the same from the instruction COUNT (4 cycles per wave64 instruction)
   lane_util       = SQ_THREAD_CYCLES_VALU / (64 SQ_ACTIVE_INST_VALU)   active lanes per issued vector instruction
   useful_issue_frac = valu_busy x lane_util                            useful lane-issue slots / all lane-issue slots
   lds_busy        = SQ_LDS_IDX_ACTIVE / (256 CUs x cycles)   (LDS-array cycles; scaled between passes by SQ_WAVE_CYCLES)
@@ -77,10 +81,16 @@ for k in kernels:
     busy, nl = val("sq_a", k, "SQ_BUSY_CYCLES")
     e["launches"] = nl
     if busy:
-        cycles = busy / 32.0
+        cycles_sq = busy / 32.0
         av, tc, waves, wca = g("SQ_ACTIVE_INST_VALU", "sq_a"), g("SQ_THREAD_CYCLES_VALU", "sq_a"), g("SQ_WAVES", "sq_a"), g("SQ_WAVE_CYCLES", "sq_a")
-        e["valu_busy_raw"] = 4.0 * av / (1024.0 * cycles)  # can pass 1: the counter charges a whole quad-cycle per instruction
-        e["valu_busy"] = min(1.0, e["valu_busy_raw"])
+        grbm, wcc = g("GRBM_GUI_ACTIVE", "sq_c"), g("SQ_WAVE_CYCLES", "sq_c")
+        cycles = grbm * (wca / wcc) if (grbm and wcc) else cycles_sq
+        e["duration_cycles_source"] = "GRBM_GUI_ACTIVE" if (grbm and wcc) else "SQ_BUSY_CYCLES/32 (sq_c pass missing)"
+        e["cycles_per_launch"] = cycles / nl
+        e["cycles_sq_per_launch"] = cycles_sq / nl
+        e["valu_busy_sq_busy_cycles"] = 4.0 * av / (1024.0 * cycles_sq)  # round 2's normalisation, for comparison
+        e["valu_busy"] = 4.0 * av / (1024.0 * cycles)
+        e["valu_issue_from_insts"] = 4.0 * g("SQ_INSTS_VALU", "sq_a") / (1024.0 * cycles)
         e["lane_util"] = tc / (64.0 * av)
         e["useful_issue_frac"] = e["valu_busy"] * e["lane_util"]
         e["valu_insts_per_launch"] = g("SQ_INSTS_VALU", "sq_a") / nl
@@ -131,7 +141,8 @@ if tr:
              "trace_avg_launch_us_one_stream": sum(e["one_stream"]["avg_us"] * e["one_stream"]["calls"] for e in tr.values() if "one_stream" in e)
                                                / max(sum(e["one_stream"]["calls"] for e in tr.values() if "one_stream" in e), 1)}
     dom = max(sec.values(), key=lambda e: e["launches"]) if sec else max(tr.values(), key=lambda e: e["launches"])
-    for key in ("valu_busy", "lane_util", "useful_issue_frac", "lds_busy", "lds_bank_conflict_share", "wait_any", "wait_inst_any", "wave_residency"):
+    for key in ("valu_busy", "valu_issue_from_insts", "valu_busy_sq_busy_cycles", "duration_cycles_source", "lane_util", "useful_issue_frac", "lds_busy",
+                "lds_bank_conflict_share", "wait_any", "wait_inst_any", "wave_residency"):
         entry[key] = dom.get(key)
     entry["counters_of"] = [k for k, e in out["kernels"].items() if e is dom][0]
     # time-weighted share of SIMD time the vector pipe issues, per stage (timed instantiations only): what bench.py turns
@@ -142,6 +153,26 @@ if tr:
         tot = sum(e["one_stream"]["total_ms"] for e in ks)
         if tot > 0:
             entry[f"valu_busy_{stage}_time_weighted"] = sum(e["valu_busy"] * e["one_stream"]["total_ms"] for e in ks) / tot
+    # frame-level HBM traffic: every timed (non-COUNT) kernel's counter bytes x launches, per rendered frame.  Frames in
+    # the profiled command = k_accum launches / accumulate launches of one step (bench line: kernel_launches_per_step)
+    try:
+        bl = json.loads(line[-1]) if line else {}
+        acc_per_step = bl.get("kernel_launches_per_step", {}).get("accum")
+        acc_total = out["kernels"].get("k_accum", {}).get("launches")
+        if acc_per_step and acc_total:
+            frames = acc_total / acc_per_step
+            def timed(k):
+                if k.startswith(("k_trace<", "k_trace_stream<")):
+                    return is_timed_trace(k)
+                return k.startswith(("k_shade", "k_accum", "k_film", "k_classify"))
+            tot = sum(e.get("hbm_bytes_per_launch", 0.0) * e["launches"] for k, e in out["kernels"].items() if timed(k) and e.get("launches"))
+            entry["frames_profiled"] = frames
+            entry["hbm_bytes_per_step"] = tot / frames
+            entry["hbm_bytes_per_step_by_stage"] = {
+                st: sum(e.get("hbm_bytes_per_launch", 0.0) * e["launches"] for k, e in out["kernels"].items() if timed(k) and k.startswith(pref) and e.get("launches")) / frames
+                for st, pref in (("trace", ("k_trace",)), ("shade", ("k_shade", "k_classify")), ("accum", ("k_accum",)), ("film", ("k_film",)))}
+    except Exception as ex:  # a profile without the bench line still summarises
+        entry["hbm_bytes_per_step_error"] = str(ex)
     ri[workload] = entry
     json.dump(ri, open(ri_path, "w"), indent=1)
     print(json.dumps(entry, indent=1))
