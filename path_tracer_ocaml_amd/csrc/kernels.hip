@@ -319,13 +319,48 @@ __device__ __forceinline__ bool pt_slab_hit_exact(const double* nb, V3 o, V3 inv
 #ifndef PT_SWZ_NEAR
 #define PT_SWZ_NEAR 1 /* 1: the LDS image also carries, per direction octant, the child the walk descends into (64-byte nodes) */
 #endif
-#if PT_SWZ_NEAR
+#ifndef PT_SWZ_SIGNSEL
+#define PT_SWZ_SIGNSEL 1 /* needs PT_SWZ_NEAR.  1: 80-byte nodes whose bounds are stored as (mn, mx, mn) per axis, node references are
+                            absolute LDS addresses */
+#endif
+#if PT_SWZ_NEAR && PT_SWZ_SIGNSEL
+/* Layout 3 (this one).  The vector pipe is what the walk is bound by, so the image is arranged to take instructions out of a
+ * visit:
+ *   bytes  0..35  per axis a: mn_a, mx_a, mn_a (binary32).  A ray reads the PAIR at 12 a + (d_a >= 0 ? 0 : 4): (near, far)
+ *                 bound of that axis for its direction sign, so t_near = fma(near, inv, n), t_far = fma(far, inv, n) need no
+ *                 min / max per axis (an fma with a fixed second and third operand is monotone in the first, so these are
+ *                 bit for bit the min and max the unselected form computes): 4 min / max per visit instead of 10
+ *   bytes 36..39  word 6 as before: branch lhs | rhs << 16, leaf first slot | real count << 16
+ *   bytes 40..43  word 7 as before: mag | axis
+ *   bytes 44..59  skip[8] u16          bytes 60..75  near[8] u16          bytes 76..79  unused
+ * and every node reference (lhs, rhs, skip, near, the walk's `node`) is the node's ABSOLUTE LDS byte address, so a visit
+ * starts reading at `node` itself (PT_SWZ_END / PT_SWZ_LEAF stay out of range: the image ends below 0xfffe). */
+#define PT_SWZ_NODE_BYTES 80
+#define PT_SWZ_OFF_LINKS 36
+#define PT_SWZ_OFF_SKIP 44
+#define PT_SWZ_OFF_NEAR 60
+typedef const __attribute__((address_space(3))) unsigned char* PtLdsPtr;
+/* native vectors (HIP's float2 class cannot be read through an address-space-qualified pointer), 4-byte aligned: the pairs
+ * start at 12 a + {0, 4} */
+typedef float pt_f2 __attribute__((ext_vector_type(2), aligned(4)));
+typedef unsigned int pt_u2 __attribute__((ext_vector_type(2), aligned(4)));
+#define PT_LDS_AT(addr) ((PtLdsPtr)(uintptr_t)(uint32_t)(addr))
+#elif PT_SWZ_NEAR
 /*   words 12..15 near[8], u16 each: for octant o the NEAR child of a branch (shape_tree.ml:209: lhs if bit `axis` of o is set,
  *               else rhs), PT_SWZ_LEAF for a leaf.  With it a visit needs no axis extraction, no bit test and no child select:
  *               next = hit an inner node ? near[o] : skip[o]. */
 #define PT_SWZ_NODE_BYTES 64
+#define PT_SWZ_OFF_LINKS 24
+#define PT_SWZ_OFF_SKIP 32
+#define PT_SWZ_OFF_NEAR 48
+#undef PT_SWZ_SIGNSEL
+#define PT_SWZ_SIGNSEL 0
 #else
 #define PT_SWZ_NODE_BYTES 48
+#define PT_SWZ_OFF_LINKS 24
+#define PT_SWZ_OFF_SKIP 32
+#undef PT_SWZ_SIGNSEL
+#define PT_SWZ_SIGNSEL 0
 #endif
 #define PT_SWZ_LEAF 0xfffeu
 #define PT_SWZ_END 0xffffu
@@ -344,6 +379,8 @@ struct PtSceneView {
   const uint32_t* skip32; /* threaded global walk: n_nodes x 8, 0xffffffff = none */
   const unsigned char* nodes32; /* 32-byte binary32 image of the nodes for the walk from HBM / L2 */
   const unsigned char* swz_nodes; /* LDS-resident scenes: the binary32 filter image, PT_SWZ_NODE_BYTES per node */
+  uint32_t swz_root;              /* what the walk's `node` is for node 0: 0 (byte offsets into the image) or, with PT_SWZ_SIGNSEL, the
+                                     image's absolute LDS address */
   const unsigned char* top;       /* scenes walked from HBM / L2: the LDS copy of PtSceneDev.top_nodes if has_top (else never dereferenced:
                                      no node reference carries PT_TOP_FLAG) */
   bool has_top;
@@ -404,6 +441,7 @@ struct PtTraverser {
   /* binary32 filter constants of the ray (SWZ only): inv32, -(o * inv)32, k2 = 2^-19 max|inv|, c2 = max|o| k2 + 2^-21 t32 */
   float fix, fiy, fiz, fnx, fny, fnz, k2, c2base, c2, t32;
   uint32_t skip_off; /* SWZ: byte offset of this ray's octant entry in a node's skip table */
+  uint32_t sel_x, sel_y, sel_z; /* PT_SWZ_SIGNSEL: byte offsets of the ray's (near, far) bound pairs */
   mutable unsigned long long n_undecided = 0, n_wave_fallbacks = 0; /* COUNT only (ptx_stats.filter_*) */
   double qa, one_over_a;
   PtTraceResult r;
@@ -432,7 +470,16 @@ struct PtTraverser {
     dirs = (d.x >= 0.0 ? 1u : 0u) | (d.y >= 0.0 ? 2u : 0u) | (d.z >= 0.0 ? 4u : 0u);
     exact_slab = !(pt_isfinite(inv.x) && pt_isfinite(inv.y) && pt_isfinite(inv.z));
     if (FILT) {
-      skip_off = 32u + 2u * dirs;
+#if PT_SWZ_SIGNSEL
+      skip_off = 2u * dirs;
+      if (SWZ) { /* where this ray's (near, far) pair of each axis starts inside a node */
+        sel_x = (dirs & 1u) ? 0u : 4u;
+        sel_y = 12u + ((dirs & 2u) ? 0u : 4u);
+        sel_z = 24u + ((dirs & 4u) ? 0u : 4u);
+      }
+#else
+      skip_off = PT_SWZ_OFF_SKIP + 2u * dirs;
+#endif
       const double ax = pt_fabs(inv.x), ay = pt_fabs(inv.y), az = pt_fabs(inv.z);
       const double imax = __builtin_fmax(ax, __builtin_fmax(ay, az));
       const double omax = __builtin_fmax(pt_fabs(o.x), __builtin_fmax(pt_fabs(o.y), pt_fabs(o.z)));
@@ -482,7 +529,7 @@ struct PtTraverser {
       one_over_a = 1.0 / qa;
     }
     sp = 0;
-    node = (G32 && sv.has_top) ? PT_TOP_FLAG : 0u; /* the root: slot 0 of the top image */
+    node = SWZ ? sv.swz_root : ((G32 && sv.has_top) ? PT_TOP_FLAG : 0u); /* the root (slot 0 of the top image) */
     walking = sc.n_nodes > 0;
     leaf_first = 0;
     leaf_n = 0;
@@ -505,6 +552,42 @@ struct PtTraverser {
     if (FILT) {
       uint4 w0, w1;
       float mag;
+#if PT_SWZ_SIGNSEL
+      if (SWZ) { /* nd is the node's absolute LDS address; the ray's sign-selected (near, far) bounds: see the layout */
+        const pt_f2 bx = *(const __attribute__((address_space(3))) pt_f2*)PT_LDS_AT(nd + sel_x);
+        const pt_f2 by = *(const __attribute__((address_space(3))) pt_f2*)PT_LDS_AT(nd + sel_y);
+        const pt_f2 bz = *(const __attribute__((address_space(3))) pt_f2*)PT_LDS_AT(nd + sel_z);
+        const pt_u2 lk = *(const __attribute__((address_space(3))) pt_u2*)PT_LDS_AT(nd + PT_SWZ_OFF_LINKS);
+        na = lk.x & 0xffffu;
+        nb = (lk.x >> 16) | ((lk.y & 3u) << 30);
+        n_real = lk.x >> 16;
+        const float tnx = __builtin_fmaf(bx.x, fix, fnx), tfx = __builtin_fmaf(bx.y, fix, fnx);
+        const float tny = __builtin_fmaf(by.x, fiy, fny), tfy = __builtin_fmaf(by.y, fiy, fny);
+        const float tnz = __builtin_fmaf(bz.x, fiz, fnz), tfz = __builtin_fmaf(bz.y, fiz, fnz);
+        const float a = __builtin_fmaxf(__builtin_fmaxf(tnx, tny), tnz);
+        const float b = __builtin_fminf(__builtin_fminf(tfx, tfy), tfz);
+        const float u = __builtin_fminf(b, t32) - __builtin_fmaxf(a, 0.0f);
+        const float m2 = __builtin_fmaf(__uint_as_float(lk.y), k2, c2);
+        hit = u >= m2;
+        if (__builtin_amdgcn_fcmpf(__builtin_fabsf(u), active ? m2 : 0.0f, 12) != 0) { /* as below */
+          const bool undecided = active && !(__builtin_fabsf(u) >= m2);
+          if (COUNT) {
+            if (undecided) n_undecided++;
+            if (pt_lane() == __ffsll((long long)__ballot(1)) - 1) n_wave_fallbacks++;
+          }
+          if (undecided) {
+            const PtNode* np = sv.nodes + (nd - sv.swz_root) / PT_SWZ_NODE_BYTES;
+            double qx = d.x, qy = d.y, qz = d.z;
+            asm volatile("" : "+v"(qx), "+v"(qy), "+v"(qz));
+            const V3 inv64 = v3(1.0 / qx, 1.0 / qy, 1.0 / qz);
+            hit = (!(pt_isfinite(inv64.x) && pt_isfinite(inv64.y) && pt_isfinite(inv64.z)))
+                      ? pt_slab_hit_exact(np->mn, o, inv64, t_min, r.t)
+                      : pt_slab_hit_fast<ORIGIN_ZERO>(np->mn, o, inv64, t_min, r.t);
+          }
+        }
+        return hit;
+      }
+#endif
       if (SWZ) { /* nd is the node's BYTE offset in the LDS image */
         w0 = *(const uint4*)(sv.swz_nodes + nd);
         w1 = *(const uint4*)(sv.swz_nodes + nd + 16);
@@ -582,7 +665,11 @@ struct PtTraverser {
     /* threaded image: where to go once this subtree is done (issued beside the node's own reads) */
     constexpr bool THREAD32 = !SWZ && std::is_same<StackT, PtThreadTag>::value;
     uint32_t skip;
+#if PT_SWZ_SIGNSEL
+    if (SWZ) skip = (uint32_t)*(const __attribute__((address_space(3))) uint16_t*)PT_LDS_AT(node + skip_off + PT_SWZ_OFF_SKIP);
+#else
     if (SWZ) skip = (uint32_t)*(const uint16_t*)(sv.swz_nodes + node + skip_off);
+#endif
     else if (!THREAD32) skip = 0u;
     else if (node & PT_TOP_FLAG) { /* top image: 16-bit byte offsets, a top node's successor is a top node */
       const uint32_t s16 = (uint32_t)*(const uint16_t*)(sv.top + (node & (PT_TOP_FLAG - 1u)) + 32u + 2u * dirs);
@@ -590,7 +677,11 @@ struct PtTraverser {
     } else skip = sv.skip32[(size_t)node * 8u + dirs];
 #if PT_SWZ_NEAR
     if (SWZ) {
+#if PT_SWZ_SIGNSEL
+      const uint32_t near_c = (uint32_t)*(const __attribute__((address_space(3))) uint16_t*)PT_LDS_AT(node + skip_off + PT_SWZ_OFF_NEAR);
+#else
       const uint32_t near_c = (uint32_t)*(const uint16_t*)(sv.swz_nodes + node + skip_off + 16u);
+#endif
       const bool hit = test_box(sv, node, na, nb, n_real);
       const bool leaf_hit = hit && near_c == PT_SWZ_LEAF;
       if (leaf_hit) {
@@ -1046,16 +1137,22 @@ __device__ __forceinline__ PtTraceResult pt_trace_packet(const PtSceneDev& sc, c
     const uint32_t d0 = (uint32_t)__builtin_amdgcn_readlane((int)tr.dirs, __ffsll((long long)remaining) - 1);
     unsigned long long m = __ballot(tr.dirs == d0) & remaining;
     remaining &= ~m;
-    uint32_t node = 0;
+    uint32_t node = SWZ ? sv.swz_root : 0u;
     int sp = 0;
     bool act = (m >> lane) & 1ull; /* this lane takes part in `node` */
     for (;;) {
       /* the node's links: one address for the whole wave */
       uint32_t ua, ub, n_real;
       if (SWZ) { /* node = byte offset in the binary32 image */
+#if PT_SWZ_SIGNSEL
+        const pt_u2 lk = *(const __attribute__((address_space(3))) pt_u2*)PT_LDS_AT(node + PT_SWZ_OFF_LINKS);
+        const uint32_t w6 = (uint32_t)__builtin_amdgcn_readfirstlane((int)lk.x);
+        const uint32_t w7 = (uint32_t)__builtin_amdgcn_readfirstlane((int)lk.y);
+#else
         const unsigned char* nbase = sv.swz_nodes + node;
-        const uint32_t w6 = (uint32_t)__builtin_amdgcn_readfirstlane((int)*(const uint32_t*)(nbase + 24));
-        const uint32_t w7 = (uint32_t)__builtin_amdgcn_readfirstlane((int)*(const uint32_t*)(nbase + 28));
+        const uint32_t w6 = (uint32_t)__builtin_amdgcn_readfirstlane((int)*(const uint32_t*)(nbase + PT_SWZ_OFF_LINKS));
+        const uint32_t w7 = (uint32_t)__builtin_amdgcn_readfirstlane((int)*(const uint32_t*)(nbase + PT_SWZ_OFF_LINKS + 4));
+#endif
         ua = w6 & 0xffffu;
         ub = (w6 >> 16) | ((w7 & 3u) << 30);
         n_real = w6 >> 16;
@@ -1156,6 +1253,7 @@ __device__ __forceinline__ PtSceneView pt_scene_view(const PtSceneDev& sc, unsig
   sv.skip32 = sc.node_skip32;
   sv.nodes32 = (const unsigned char*)sc.nodes32;
   sv.swz_nodes = nullptr;
+  sv.swz_root = 0u;
   sv.top = lds_raw;
   sv.has_top = false;
   if (!LDS_SCENE && want_top && sc.n_top > 0) { /* the tree's top into LDS (the caller's barrier follows) */
@@ -1181,29 +1279,43 @@ __device__ __forceinline__ PtSceneView pt_scene_view(const PtSceneDev& sc, unsig
     double* l_tri = (double*)(lds_raw + off);
     if (MODE == PT_MODE_ARRAY && sc.has_triangles) off += (size_t)total_slots * 10 * sizeof(double);
     uint8_t* l_kind = (uint8_t*)(lds_raw + off);
-    /* nodes: the binary32 filter image (PT_SWZ_NODE_BYTES each); links become byte offsets into it */
+    /* nodes: the binary32 filter image (PT_SWZ_NODE_BYTES each); links become byte offsets into it -- with PT_SWZ_SIGNSEL,
+     * absolute LDS addresses (layout 3 above) */
+#if PT_SWZ_SIGNSEL
+    const uint32_t nbase = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)l_nodes;
+#else
+    const uint32_t nbase = 0u;
+#endif
     for (int k = threadIdx.x; k < sc.n_nodes; k += blockDim.x) {
       const PtNode* src = sc.nodes + k;
       uint32_t* w = (uint32_t*)(l_nodes + (size_t)k * PT_SWZ_NODE_BYTES);
       float mag = 0.0f;
       for (int ax = 0; ax < 3; ++ax) {
         const float lo = (float)src->mn[ax], hi = (float)src->mx[ax];
+#if PT_SWZ_SIGNSEL
+        w[3 * ax] = __float_as_uint(lo);
+        w[3 * ax + 1] = __float_as_uint(hi);
+        w[3 * ax + 2] = __float_as_uint(lo);
+#else
         w[ax] = __float_as_uint(lo);
         w[3 + ax] = __float_as_uint(hi);
+#endif
         mag = __builtin_fmaxf(mag, __builtin_fmaxf(__builtin_fabsf(lo), __builtin_fabsf(hi)));
       }
       const uint32_t axis = src->b >> 30;
       const bool leaf = axis == PT_NODE_LEAF_AXIS;
-      w[6] = leaf ? ((src->a & 0xffffu) | ((src->pad[0] & 0xffffu) << 16))
-                  : ((src->a * PT_SWZ_NODE_BYTES) | (((src->b & 0x3fffffffu) * PT_SWZ_NODE_BYTES) << 16));
+      uint32_t* lk = w + PT_SWZ_OFF_LINKS / 4;
+      lk[0] = leaf ? ((src->a & 0xffffu) | ((src->pad[0] & 0xffffu) << 16))
+                   : ((nbase + src->a * PT_SWZ_NODE_BYTES) | ((nbase + (src->b & 0x3fffffffu) * PT_SWZ_NODE_BYTES) << 16));
       /* rounded up, then the two lowest mantissa bits carry the axis (a relative change below 2^-21, inside the slack) */
-      w[7] = ((__float_as_uint(mag * 1.000001f) + 4u) & ~3u) | axis;
-      uint16_t* sk = (uint16_t*)(w + 8);
+      lk[1] = ((__float_as_uint(mag * 1.000001f) + 4u) & ~3u) | axis;
+      uint16_t* sk = (uint16_t*)((unsigned char*)w + PT_SWZ_OFF_SKIP);
       for (int o = 0; o < 8; ++o) {
         const uint32_t nx = sc.node_skip[(size_t)k * 8 + o];
-        sk[o] = nx == 0xffffu ? (uint16_t)PT_SWZ_END : (uint16_t)(nx * PT_SWZ_NODE_BYTES);
+        sk[o] = nx == 0xffffu ? (uint16_t)PT_SWZ_END : (uint16_t)(nbase + nx * PT_SWZ_NODE_BYTES);
 #if PT_SWZ_NEAR
-        sk[8 + o] = leaf ? (uint16_t)PT_SWZ_LEAF : (uint16_t)((((o >> axis) & 1) ? src->a : (src->b & 0x3fffffffu)) * PT_SWZ_NODE_BYTES);
+        uint16_t* nr = (uint16_t*)((unsigned char*)w + PT_SWZ_OFF_NEAR);
+        nr[o] = leaf ? (uint16_t)PT_SWZ_LEAF : (uint16_t)(nbase + (((o >> axis) & 1) ? src->a : (src->b & 0x3fffffffu)) * PT_SWZ_NODE_BYTES);
 #endif
       }
     }
@@ -1222,6 +1334,7 @@ __device__ __forceinline__ PtSceneView pt_scene_view(const PtSceneDev& sc, unsig
     }
     __syncthreads();
     sv.swz_nodes = l_nodes;
+    sv.swz_root = nbase;
     sv.sph = l_sph;
     sv.tri = l_tri;
     sv.kind = l_kind;
@@ -1644,7 +1757,13 @@ __global__ __launch_bounds__(PT_TRACE_BLOCK_OF(MODE, LDS_SCENE), PT_TRACE_GLOBAL
           if (COUNT) c_seg++;
           V3 ro, rd;
           pt_q_load_ray(q, i, ro, rd);
-          tr.begin(sc, sv, ro, rd, c_floor);
+          if (pt_is_hole(rd.x)) { /* an unused entry of a blocked queue (k_shade_pool): recorded and dropped, the lane stays idle */
+            hits.slot[i] = PT_SLOT_HOLE;
+            ray = 0xffffffffu;
+            if (COUNT) c_seg--;
+          } else {
+            tr.begin(sc, sv, ro, rd, c_floor);
+          }
         }
       }
       pos += (uint32_t)__popcll(im);
