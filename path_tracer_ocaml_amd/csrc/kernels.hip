@@ -332,10 +332,13 @@ __device__ __forceinline__ bool pt_slab_hit_exact(const double* nb, V3 o, V3 inv
  *                 bit for bit the min and max the unselected form computes): 4 min / max per visit instead of 10
  *   bytes 36..39  word 6 as before: branch lhs | rhs << 16, leaf first slot | real count << 16
  *   bytes 40..43  word 7 as before: mag | axis
- *   bytes 44..59  skip[8] u16          bytes 60..75  near[8] u16          bytes 76..79  unused
+ *   bytes 44..59  skip[8] u16          bytes 60..75  near[8] u16          bytes 76..83  unused (see PT_SWZ_NODE_BYTES)
  * and every node reference (lhs, rhs, skip, near, the walk's `node`) is the node's ABSOLUTE LDS byte address, so a visit
  * starts reading at `node` itself (PT_SWZ_END / PT_SWZ_LEAF stay out of range: the image ends below 0xfffe). */
-#define PT_SWZ_NODE_BYTES 80
+#ifndef PT_SWZ_NODE_BYTES
+#define PT_SWZ_NODE_BYTES 92 /* 80 used + 12: 23 words, an ODD stride, so that node k starts in LDS bank 21 k mod 64 -- all 64 banks.
+                                With 80 bytes (20 words) the nodes start in 16 of the 64 banks only, with 64 bytes in 4 */
+#endif
 #define PT_SWZ_OFF_LINKS 36
 #define PT_SWZ_OFF_SKIP 44
 #define PT_SWZ_OFF_NEAR 60
@@ -363,6 +366,12 @@ typedef unsigned int pt_u2 __attribute__((ext_vector_type(2), aligned(4)));
 #define PT_SWZ_SIGNSEL 0
 #endif
 #define PT_SWZ_LEAF 0xfffeu
+/* doubles per sphere slot in the LDS copy: 4 used ({x, y, z, r}) + padding.  With 4 (8 words) a slot starts in 8 of the 64 banks
+ * only; with 6 (12 words) in 16.  Global memory keeps 4. */
+#ifndef PT_LDS_SPH_DOUBLES
+#define PT_LDS_SPH_DOUBLES 4
+#endif
+#define PT_SPH_STRIDE(SWZ_) ((SWZ_) ? PT_LDS_SPH_DOUBLES : 4)
 #define PT_SWZ_END 0xffffu
 /* bytes of LDS a wave keeps for traversal stacks: LDS-resident scenes walk the threaded image (no per-lane stack) and
  * only the camera-ray packet walk keeps its shared (node, mask) stack there: 12 bytes per level, rounded to 16 */
@@ -830,7 +839,7 @@ struct PtTraverser {
             c_nodes++;
             PT_DIAG_WAVE_SLOTS(c_floor);
           }
-          const double* s = sv.sph + (size_t)(leaf_first + base + k) * 4;
+          const double* s = sv.sph + (size_t)(leaf_first + base + k) * PT_SPH_STRIDE(SWZ);
           const double fx = ORIGIN_ZERO ? s[0] : s[0] - o.x, fy = ORIGIN_ZERO ? s[1] : s[1] - o.y,
                        fz = ORIGIN_ZERO ? s[2] : s[2] - o.z;
           const double bp_over_a = pt_fma(fx, d.x, pt_fma(fy, d.y, fz * d.z)) * one_over_a;
@@ -847,7 +856,7 @@ struct PtTraverser {
           }
           const int k = __ffs((int)cand) - 1;
           cand &= cand - 1u;
-          const double* s = sv.sph + (size_t)(leaf_first + base + k) * 4;
+          const double* s = sv.sph + (size_t)(leaf_first + base + k) * PT_SPH_STRIDE(SWZ);
           const double fx = ORIGIN_ZERO ? s[0] : s[0] - o.x, fy = ORIGIN_ZERO ? s[1] : s[1] - o.y,
                        fz = ORIGIN_ZERO ? s[2] : s[2] - o.z;
           const double r2 = s[3] * s[3];
@@ -877,7 +886,7 @@ struct PtTraverser {
             c_nodes++;
             PT_DIAG_WAVE_SLOTS(c_floor);
           }
-          const double* s = sv.sph + (size_t)(leaf_first + k) * 4;
+          const double* s = sv.sph + (size_t)(leaf_first + k) * PT_SPH_STRIDE(SWZ);
           const double fx = ORIGIN_ZERO ? s[0] : s[0] - o.x, fy = ORIGIN_ZERO ? s[1] : s[1] - o.y,
                        fz = ORIGIN_ZERO ? s[2] : s[2] - o.z; /* f = center - origin */
           const double r2 = s[3] * s[3];
@@ -943,7 +952,7 @@ struct PtTraverser {
         }
         const int slot = leaf_first + k;
         if (sv.kind[slot] == PT_SLOT_SPHERE) {
-          const double* s = sv.sph + (size_t)slot * 4;
+          const double* s = sv.sph + (size_t)slot * PT_SPH_STRIDE(SWZ);
           double t;
           if (pt_sphere_intersect_scalar(v3(s[0], s[1], s[2]), s[3], o, d, t_min, r.t, &t)) {
             r.t = t;
@@ -1179,7 +1188,7 @@ __device__ __forceinline__ PtTraceResult pt_trace_packet(const PtSceneDev& sc, c
              * leaf's box; the roots only where a ray's discriminant is >= +0 (same order per ray as packet()) */
             const double t_min = 0.0;
             for (uint32_t k = 0; k < n_real; ++k) {
-              const double* sp4 = sv.sph + (size_t)(ua + k) * 4;
+              const double* sp4 = sv.sph + (size_t)(ua + k) * PT_SPH_STRIDE(SWZ);
               /* f = center - origin; for camera rays the origin is (+0, +0, +0) and x - (+0) == x bit for bit */
               const double fx = ORIGIN_ZERO ? sp4[0] : sp4[0] - tr.o.x, fy = ORIGIN_ZERO ? sp4[1] : sp4[1] - tr.o.y,
                            fz = ORIGIN_ZERO ? sp4[2] : sp4[2] - tr.o.z;
@@ -1272,10 +1281,10 @@ __device__ __forceinline__ PtSceneView pt_scene_view(const PtSceneDev& sc, unsig
   if (LDS_SCENE) {
     size_t off = ((size_t)waves_per_block * PT_WAVE_STACK_BYTES(LDS_SCENE, StackT, stack_depth) + 63) & ~(size_t)63;
     unsigned char* l_nodes = lds_raw + off;
-    off += (size_t)sc.n_nodes * PT_SWZ_NODE_BYTES;
+    off += ((size_t)sc.n_nodes * PT_SWZ_NODE_BYTES + 63) & ~(size_t)63; /* (the packets behind it are read 16 bytes at a time) */
     const int total_slots = sc.n_slots + sc.n_floor;
     double* l_sph = (double*)(lds_raw + off);
-    off += (size_t)total_slots * 4 * sizeof(double);
+    off += (size_t)total_slots * PT_LDS_SPH_DOUBLES * sizeof(double);
     double* l_tri = (double*)(lds_raw + off);
     if (MODE == PT_MODE_ARRAY && sc.has_triangles) off += (size_t)total_slots * 10 * sizeof(double);
     uint8_t* l_kind = (uint8_t*)(lds_raw + off);
@@ -1322,7 +1331,7 @@ __device__ __forceinline__ PtSceneView pt_scene_view(const PtSceneDev& sc, unsig
     {
       const uint4* src = (const uint4*)sc.sph;
       uint4* dst = (uint4*)l_sph;
-      for (int k = threadIdx.x; k < total_slots * 2; k += blockDim.x) dst[k] = src[k];
+      for (int k = threadIdx.x; k < total_slots * 2; k += blockDim.x) dst[(k >> 1) * (PT_LDS_SPH_DOUBLES / 2) + (k & 1)] = src[k];
     }
     if (MODE == PT_MODE_ARRAY) {
       if (sc.has_triangles) {

@@ -6,7 +6,8 @@ usage: tools/summarize_sq.py gpurun_out/r02_shirley r02 shirley_1080p_spp64_d8
 
 Derived figures (MI355X_MICROARCH.md, "rocprofv3 PMC slots": SQ_*_CYCLES and SQ_ACTIVE_INST_* count quad-cycles;
 SQ_BUSY_CYCLES counts cycles once per shader engine, 32 of them):
-  cycles          = GRBM_GUI_ACTIVE of the kernel's dispatches (sq_c pass, scaled to the sq_a pass by SQ_WAVE_CYCLES): the
+  cycles          = GRBM_GUI_ACTIVE / 8 (summed over the 8 XCDs by the profiler) of the kernel's dispatches (sq_c pass, scaled to the
+                    sq_a pass by SQ_WAVE_CYCLES): the
                     kernel's duration in shader cycles, summed over launches.  SQ_BUSY_CYCLES / 32 (one count per shader
                     engine) is kept as cycles_sq: it UNDER-counts the duration by >= 10 % on kernels that keep every engine
                     busy (round 2 got valu_busy 1.115 from it and clamped); no figure below is clamped any more
@@ -84,7 +85,8 @@ for k in kernels:
         cycles_sq = busy / 32.0
         av, tc, waves, wca = g("SQ_ACTIVE_INST_VALU", "sq_a"), g("SQ_THREAD_CYCLES_VALU", "sq_a"), g("SQ_WAVES", "sq_a"), g("SQ_WAVE_CYCLES", "sq_a")
         grbm, wcc = g("GRBM_GUI_ACTIVE", "sq_c"), g("SQ_WAVE_CYCLES", "sq_c")
-        cycles = grbm * (wca / wcc) if (grbm and wcc) else cycles_sq
+        # rocprofv3 sums GRBM_GUI_ACTIVE over the 8 XCDs of the MI355X (each XCD's GRBM counts its own busy cycles): / 8
+        cycles = grbm / 8.0 * (wca / wcc) if (grbm and wcc) else cycles_sq
         e["duration_cycles_source"] = "GRBM_GUI_ACTIVE" if (grbm and wcc) else "SQ_BUSY_CYCLES/32 (sq_c pass missing)"
         e["cycles_per_launch"] = cycles / nl
         e["cycles_sq_per_launch"] = cycles_sq / nl
