@@ -8,6 +8,10 @@ materials) is resident in HBM before the timed region; the framebuffer stays on 
 
 N > 1: the SAME image, rows dealt to ranks in interleaved 8-row bands (strong scaling), one group of
 point-to-point sends (RCCL over xGMI) of the raw sums into rank 0 per step; the film reads the bands in place.
+Started as the driver does (`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`, WORLD_SIZE set) each
+process is one rank; started plainly (`python bench.py --gpus N`, no WORLD_SIZE) it launches that command itself -- N fresh
+child processes, before this process imports torch or touches a GPU -- and relays rank 0's line and the exit code
+(launch_ranks).  `--rehearse-launch` runs the same launch + band exchange on the CPU over gloo (no render, `value` null).
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with "roofline" and "cpu_baseline".
 
@@ -62,6 +66,11 @@ def algorithmic_bytes(stats, spp, triangles):
 
 FLOP_PER_NODE_TEST = 27.0   # Bbox.is_hit: 6 sub, 6 mul, 12 min/max, 2 clamps, 1 compare (bbox.ml:40-56)
 FLOP_PER_SLOT_SCAN = 24.0   # spheres_intersect_aux up to the discriminant (lib.rs:115-160); triangles: Moller-Trumbore ~ the same
+# k_bounce also shades what it traced: the reference's arithmetic per segment outside Scene.intersect, counted like the two above
+# (add / mul / fma-as-2 / div / sqrt / compare = 1 each, a transcendental = 1): a surface hit ~135 (Ray.point_at 6, normal 12 + facing 5,
+# Shader_space rotation ~20, two quaternion transforms 2 x 33, Material.scatter + Pdf sample ~15, new ray + attenuation ~14),
+# a miss ~25 (unit direction + background lerp); 100 = the headline scene's 0.61 : 0.39 mix.  An approximation, stated as such.
+FLOP_PER_SEGMENT_SHADE = 100.0
 F64_VECTOR_PEAK_TFLOPS = 78.6  # MI355X binary64 vector peak = half the 157.3 TFLOP/s binary32 figure (MI355X_MICROARCH.md)
 
 
@@ -319,8 +328,11 @@ def main():
             del os.environ["PTX_STREAMS"]
         else:
             os.environ["PTX_STREAMS"] = prev_streams
-    kernel_ms = {k: st1["kernel_ms"][k] for k in ("generate", "trace", "shade", "accum", "film")}
+    kernel_ms = {k: st1["kernel_ms"][k] for k in ("generate", "trace", "shade", "bounce", "accum", "film")}
     launches = {k: st1["kernel_launches"][k] for k in kernel_ms}
+    # the dominant kernel: k_bounce (walk + shade of one bounce in one launch) where the scene's tree fits LDS, else k_trace
+    fused = launches["bounce"] > 0
+    dom = "bounce" if fused else "trace"
     cdev = dev if args.backend == "nccl" else torch.device("cpu")  # where the tiny control tensors live
     t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
     if world > 1:
@@ -332,7 +344,7 @@ def main():
                               passes_per_batch=args.passes_per_batch)
     cst = scene.render_raw_device(cparams, part.data_ptr(), stream)
     keys = ("samples", "segments", "nodes_tested", "prims_tested", "floor_tested")
-    cvec = torch.tensor([float(cst[k]) for k in keys] + [kernel_ms["trace"], launches["trace"]], dtype=torch.float64, device=cdev)
+    cvec = torch.tensor([float(cst[k]) for k in keys] + [kernel_ms[dom], launches[dom]], dtype=torch.float64, device=cdev)
     if world > 1:
         # counters: sum over ranks; trace time: the slowest rank bounds the job, launches: per rank
         summed = cvec.clone()
@@ -359,20 +371,27 @@ def main():
             copy_gbs = measured_hbm_copy_gbs(torch, dev)
         except Exception:
             copy_gbs = None
-        alg_flop = counts["nodes_tested"] * FLOP_PER_NODE_TEST + (counts["prims_tested"] + counts["floor_tested"]) * FLOP_PER_SLOT_SCAN
+        walk_flop = counts["nodes_tested"] * FLOP_PER_NODE_TEST + (counts["prims_tested"] + counts["floor_tested"]) * FLOP_PER_SLOT_SCAN
+        shade_flop = counts["segments"] * FLOP_PER_SEGMENT_SHADE if fused else 0.0  # k_trace does not shade
+        alg_flop = walk_flop + shade_flop
         flops_achieved = alg_flop / (trace_ms_step * 1e-3) * 1e-12 if trace_ms_step > 0 else 0.0
         bytes_achieved = b_trace / (trace_ms_step * 1e-3) * 1e-9 if trace_ms_step > 0 else 0.0
         hbm_block = {"traffic": traffic, "achieved": (traffic / avg_launch_s * 1e-9) if (traffic and avg_launch_s > 0) else None,
                      "peak": HBM_PEAK_GBS * world, "unit": "GB/s", "peak_measured_copy": copy_gbs,
                      "source": tc.get("source", "not profiled"),
-                     "note": "HBM bytes per k_trace launch from rocprofv3 counters (2 x FETCH_SIZE + WRITE_SIZE), over the live launch duration"}
+                     "note": "HBM bytes per launch of the dominant kernel from rocprofv3 counters (2 x FETCH_SIZE + WRITE_SIZE), over the live launch duration"}
         hbm_block["frac"] = (hbm_block["achieved"] / hbm_block["peak"]) if hbm_block["achieved"] else None
         if in_lds:
             # tree + packets are LDS-resident: node / slot reads never reach HBM, the binding pipe is vector issue
-            roofline = {"bound": "valu_f64", "kernel": "k_trace", "achieved": flops_achieved, "peak": F64_VECTOR_PEAK_TFLOPS * world,
+            roofline = {"bound": "valu_f64", "kernel": "k_bounce (walk + shade of a bounce in one launch)" if fused else "k_trace", "achieved": flops_achieved, "peak": F64_VECTOR_PEAK_TFLOPS * world,
                         "unit": "TFLOP/s", "frac": flops_achieved / (F64_VECTOR_PEAK_TFLOPS * world), "traffic": traffic,
                         "algorithmic_flop_per_launch": alg_flop / n_launch,
-                        "flop_model": f"{FLOP_PER_NODE_TEST:g} per Bbox.is_hit + {FLOP_PER_SLOT_SCAN:g} per packet slot scanned (reference arithmetic, binary64)",
+                        "flop_model": f"{FLOP_PER_NODE_TEST:g} per Bbox.is_hit + {FLOP_PER_SLOT_SCAN:g} per packet slot scanned (reference arithmetic, binary64)"
+                                      + (f" + {FLOP_PER_SEGMENT_SHADE:g} per segment shaded (approximate)" if fused else ""),
+                        "algorithmic_flop_per_step": {"walk": walk_flop, "shade": shade_flop},
+                        "walk_only": {"achieved": walk_flop / (trace_ms_step * 1e-3) * 1e-12 if trace_ms_step > 0 else 0.0,
+                                      "frac": walk_flop / (trace_ms_step * 1e-3) * 1e-12 / (F64_VECTOR_PEAK_TFLOPS * world) if trace_ms_step > 0 else 0.0,
+                                      "note": "the walk's flops alone over the same kernel time: the figure earlier rounds quoted for k_trace, now over a kernel that also shades"} if fused else None,
                         "issue": {k: tc.get(k) for k in ("valu_busy", "valu_issue_from_insts", "lane_util", "useful_issue_frac", "lds_busy", "lds_bank_conflict_share", "duration_cycles_source", "source")},
                         "hbm": hbm_block}
         else:
@@ -389,27 +408,37 @@ def main():
                          "pipeline": {"bytes_per_sample": b_total / samples, "achieved": b_total * args.steps / elapsed * 1e-9,
                                       "unit": "GB/s (algorithmic, SURVEY section 8 D)"}})
         # second kernel: the shade stage moves the bytes.  Algorithmic HBM bytes of one step: every
-        # segment reads its queue entry (ray 48 B + path state 32 B [+ carried emission 32 B]) and its hit record (12 B);
+        # segment reads its queue entry (ray 48 B + path state 32 B [+ carried emission 32 B]) and its hit record (t + slot 12 B; 36 B where triangles carry u, v);
         # a segment that survives writes the next entry (80 B [+ 32 B]), a path that ends writes one 32-byte contribution.
         # survivors = segments - samples (every segment after a path's first was written by a survivor).
         emit_b = 32 if scene_name == "cornell" else 0
+        hit_b = 12 if scene_name == "shirley" else 36  # t + slot; scenes with triangles: one 32-byte {t, u, v} record + slot (PtHits)
         segs = counts["segments"]
-        shade_bytes = segs * (80 + emit_b + 12) + max(segs - counts["samples"], 0) * (80 + emit_b) + counts["samples"] * 32
+        shade_bytes = segs * (80 + emit_b + hit_b) + max(segs - counts["samples"], 0) * (80 + emit_b) + counts["samples"] * 32
         shade_s = kernel_ms["shade"] * 1e-3  # rank 0's share; the ranks run side by side, so job bytes / this = aggregate rate
         shade_gbs = shade_bytes / shade_s * 1e-9 if shade_s > 0 else None
-        roofline["shade"] = {"bound": "hbm", "kernel": "k_shade_pool", "achieved": shade_gbs, "peak": HBM_PEAK_GBS * world, "unit": "GB/s",
-                             "frac": (shade_gbs / (HBM_PEAK_GBS * world)) if shade_gbs else None,
-                             "algorithmic_bytes_per_step": shade_bytes, "ms_per_step_one_stream": kernel_ms["shade"],
-                             "timing": "HIP events on the launch stream, one-stream pass (PTX_STREAMS=1)"}
+        if shade_s > 0 and not fused:
+            roofline["shade"] = {"bound": "hbm", "kernel": "k_shade_pool", "achieved": shade_gbs, "peak": HBM_PEAK_GBS * world, "unit": "GB/s",
+                                 "frac": (shade_gbs / (HBM_PEAK_GBS * world)) if shade_gbs else None,
+                                 "algorithmic_bytes_per_step": shade_bytes, "ms_per_step_one_stream": kernel_ms["shade"],
+                                 "timing": "HIP events on the launch stream, one-stream pass (PTX_STREAMS=1)"}
+        if fused:
+            # the same kernel against HBM: what a bounce must move -- the queue entry in, the survivor's entry out or the
+            # path's contribution; the hit record stays inside the wave (its 4-byte slot never reaches memory, t goes through L2)
+            bounce_bytes = shade_bytes - segs * 4
+            bs = kernel_ms["bounce"] * 1e-3
+            roofline["bytes"] = {"bound": "hbm", "kernel": "k_bounce", "achieved": bounce_bytes / bs * 1e-9 if bs > 0 else None,
+                                 "peak": HBM_PEAK_GBS * world, "unit": "GB/s", "frac": bounce_bytes / bs * 1e-9 / (HBM_PEAK_GBS * world) if bs > 0 else None,
+                                 "algorithmic_bytes_per_step": bounce_bytes, "ms_per_step_one_stream": kernel_ms["bounce"]}
         # how much of the step the vector pipe is busy: sum over stages of (one-stream kernel time x the stage's tracked
         # SQ_ACTIVE_INST_VALU share) against the step as timed.  Trace and shade of two batches run side by side on every
         # CU, so this -- not either kernel's own roofline -- is what the frame converges to.
-        vb_t, vb_s = tc.get("valu_busy_trace_time_weighted"), tc.get("valu_busy_shade_time_weighted")
-        if vb_t is not None and vb_s is not None:
-            valu_ms = kernel_ms["trace"] * vb_t + kernel_ms["shade"] * vb_s
+        vb = {st_: tc.get(f"valu_busy_{st_}_time_weighted") for st_ in ("trace", "shade", "bounce")}
+        if all(vb[st_] is not None for st_ in vb if kernel_ms[st_] > 0) and any(kernel_ms[st_] > 0 for st_ in vb):
+            valu_ms = sum(kernel_ms[st_] * vb[st_] for st_ in vb if kernel_ms[st_] > 0)
             roofline["frame"] = {"bound": "valu_issue", "valu_busy_ms_per_step": valu_ms, "ms_per_step": ms_per_step,
                                  "frac": valu_ms / ms_per_step if ms_per_step > 0 else None,
-                                 "valu_busy_share": {"trace": vb_t, "shade": vb_s}, "source": tc.get("source"),
+                                 "valu_busy_share": {st_: vb[st_] for st_ in vb if kernel_ms[st_] > 0}, "source": tc.get("source"),
                                  "note": "vector-pipe busy time of the step's kernels (one-stream durations x tracked counter shares) / the step"}
         # frame-level HBM traffic: counter-measured bytes of every kernel of a step (tracked profile) over the step as timed here
         hb = tc.get("hbm_bytes_per_step")

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define PTX_ABI_VERSION 3
+#define PTX_ABI_VERSION 4
 
 /* ---- materials: Material.t, path_tracer/src/material.ml:3-14 ---- */
 #define PTX_MAT_LAMBERTIAN 0 /* Lambertian of Texture.t */
@@ -154,7 +154,8 @@ typedef struct ptx_render_params {
 #define PTX_KERNEL_SHADE 2
 #define PTX_KERNEL_ACCUM 3
 #define PTX_KERNEL_FILM 4
-#define PTX_N_KERNELS 5
+#define PTX_KERNEL_BOUNCE 5 /* trace + shade of one bounce in ONE launch (scenes whose tree fits LDS); then TRACE / SHADE count only what ran separately */
+#define PTX_N_KERNELS 6
 
 typedef struct ptx_stats {
   int64_t samples;       /* W * rows * spp actually rendered */

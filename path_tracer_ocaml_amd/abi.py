@@ -5,14 +5,14 @@ checks the sizes against the compiled library.
 """
 import ctypes as C
 
-PTX_ABI_VERSION = 3
+PTX_ABI_VERSION = 4
 
 PTX_MAT_LAMBERTIAN, PTX_MAT_METAL, PTX_MAT_DIELECTRIC = 0, 1, 2
 PTX_TEX_SOLID, PTX_TEX_CHECKER = 0, 1
 PTX_BG_BLACK, PTX_BG_SKY = 0, 1
 PTX_LEAF_SIMD, PTX_LEAF_ARRAY = 0, 1
-PTX_KERNEL_NAMES = ("generate", "trace", "shade", "accum", "film")
-PTX_N_KERNELS = 5
+PTX_KERNEL_NAMES = ("generate", "trace", "shade", "accum", "film", "bounce")
+PTX_N_KERNELS = 6
 
 c_double_p = C.POINTER(C.c_double)
 c_int32_p = C.POINTER(C.c_int32)

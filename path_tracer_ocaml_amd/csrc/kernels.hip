@@ -27,7 +27,14 @@
 /* A queue entry is two records: the ray (what k_trace reads, densely) and the rest of the path's state (what only the shade
  * stage reads, entry by entry in the order its category pools dictate -- one 32-byte sector instead of five 8-byte fields in
  * five different sectors).  Both are multiples of 16 bytes: every access is a 16-byte load or store. */
+#ifndef PT_RAY_PAD
+#define PT_RAY_PAD 0
+#endif
+#if PT_RAY_PAD
+struct PtRayRec { double ox, oy, oz, dx, dy, dz, pad0, pad1; };      /* experiment: one 64-byte line per ray */
+#else
 struct PtRayRec { double ox, oy, oz, dx, dy, dz; };                  /* 48 B: ray origin, direction */
+#endif
 struct PtPathRec { double ar, ag, ab; uint32_t id; int32_t offset; }; /* 32 B: attn0 (integrator.ml:30); slot in the batch's
                                                                          contribution buffer; sampler offset = gy*W + gx + pass*spp
                                                                          (integrator.ml:98) */
@@ -1432,6 +1439,12 @@ struct PtChunkFeed {
 #ifndef PT_TRACE_GLOBAL_WAVES
 #define PT_TRACE_GLOBAL_WAVES 4
 #endif
+#ifndef PT_TRACE_PRIO
+#define PT_TRACE_PRIO 0 /* s_setprio of the trace / pooled shade waves (0..3): matters only where both share a SIMD (two batches) */
+#endif
+#ifndef PT_SHADE_PRIO
+#define PT_SHADE_PRIO 0
+#endif
 #ifndef PT_TAIL_CUT
 #define PT_TAIL_CUT 16 /* 0 = off */
 #endif
@@ -1461,6 +1474,9 @@ __global__ __launch_bounds__(PT_TRACE_BLOCK_OF(MODE, LDS_SCENE), (LDS_SCENE && M
                                                PtCounters* counters, PtGenParams g, const double* __restrict__ alpha,
                                                uint32_t n_primary, uint32_t* work, uint4* susp, int top_in_lds) {
   extern __shared__ __attribute__((aligned(64))) unsigned char lds_raw[];
+#if PT_TRACE_PRIO
+  __builtin_amdgcn_s_setprio(PT_TRACE_PRIO);
+#endif
   const int lane = pt_lane();
   const int wave_in_block = (int)(threadIdx.x >> 6);
   /* LDS-resident scenes have < 65536 nodes: 16-bit stack entries halve the stack footprint */
@@ -2510,6 +2526,9 @@ __global__ __launch_bounds__(PT_POOL_THREADS, PT_SHADE_WAVES) void k_shade_pool(
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_pool_raw[]; /* [waves][PT_N_SHADE_CAT][128] x (queue index, hit slot) */
   __shared__ uint32_t lds_out[PT_POOL_BINS];
   __shared__ uint32_t lds_chunk_ctr, lds_done;
+#if PT_SHADE_PRIO
+  __builtin_amdgcn_s_setprio(PT_SHADE_PRIO);
+#endif
   const int lane = pt_lane(), wave = (int)(threadIdx.x >> 6), nw = (int)(blockDim.x >> 6);
   const uint32_t n = PRIMARY ? n_primary : *q.count;
   const uint32_t total_chunks = (uint32_t)(((unsigned long long)n + PT_WAVE - 1) / PT_WAVE);
@@ -2638,6 +2657,230 @@ __global__ __launch_bounds__(PT_POOL_THREADS, PT_SHADE_WAVES) void k_shade_pool(
   if (lane == 0) done = __hip_atomic_fetch_add(&lds_done, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
   done = (uint32_t)__builtin_amdgcn_readfirstlane((int)done);
   if (done != (uint32_t)(nw - 1)) return;
+  for (int b = 0; b < PT_POOL_BINS; ++b) {
+    const uint32_t st = __hip_atomic_load(lds_out + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    const uint32_t blk = st >> 12, pos = st & 0xfffu;
+    if (blk == PT_POOL_NO_BLOCK) continue;
+    for (uint32_t e = pos + (uint32_t)lane; e < (uint32_t)PT_POOL_BLOCK; e += PT_WAVE)
+      out.ray[(size_t)blk * PT_POOL_BLOCK + e].dx = __hiloint2double((int)PT_HOLE_HI, 0);
+  }
+}
+
+/* ------------------------------------------------------------------ one kernel per bounce (LDS-resident scenes)
+ * k_trace and k_shade_pool of two batches share every CU so that one batch's vector-bound walk fills the other's waits for
+ * memory -- but a 128-VGPR shade wave that waits two thirds of its life holds its quarter of the register file while it
+ * does, and the split 4 trace + 2 shade waves per SIMD halves the shade stage's own latency hiding (the frame gained 6 % over
+ * running the two kernels one after the other).  k_bounce is both stages in ONE wave: it walks a chunk of
+ * 64 queued rays (pt_trace_ray, tail cut and parked walks exactly as in k_trace), files the finished rays in its
+ * per-category pools, and whenever a pool holds 64 entries shades them (pt_shade_entry, pt_pool_push exactly as in
+ * k_shade_pool).  Every wave of the CU then spends most of its life walking, the waits of a wave that shades are covered by
+ * the three others on its SIMD, the hit slot never goes through memory, and a bounce is one launch.  One 1024-thread
+ * workgroup per CU: [stacks][scene image][16 waves x 5 pools] in LDS.  Same tests in the same order per ray, same
+ * arithmetic per segment: the results are those of the two-kernel path bit for bit. */
+#ifndef PT_BOUNCE_THREADS
+#define PT_BOUNCE_THREADS 1024
+#endif
+#ifndef PT_BOUNCE_MIN_CHUNKS
+#define PT_BOUNCE_MIN_CHUNKS 2 /* chunks per wave below which fewer workgroups take part (k_shade_pool: 16 -- there a chunk is a few microseconds) */
+#endif
+#ifndef PT_BOUNCE_PREFETCH
+#define PT_BOUNCE_PREFETCH 0 /* a wave holds the chunk it will walk NEXT and has touched its ray records (one dword per lane covers every line) */
+#endif
+#ifndef PT_BOUNCE_FENCE_WG
+#define PT_BOUNCE_FENCE_WG 0 /* 1: workgroup-scope fences (s_waitcnt vmcnt(0)) around the wave's own hit / parked records instead of wavefront scope */
+#endif
+template <int MODE, bool COUNT, bool EMIT, bool PRIMARY>
+__global__ __launch_bounds__(PT_BOUNCE_THREADS, 4) void k_bounce(PtSceneDev sc, PtQueue q, PtHits hits, PtQueue out, PtContrib contrib,
+                                                                 const double* __restrict__ alpha, int bounce, int last_bounce, PtGenParams g,
+                                                                 uint32_t n_primary, int stack_depth, uint32_t pool_off, uint4* susp,
+                                                                 PtCounters* counters) {
+  extern __shared__ __attribute__((aligned(64))) unsigned char lds_raw[];
+  __shared__ uint32_t lds_out[PT_POOL_BINS];
+  __shared__ uint32_t lds_chunk_ctr, lds_done;
+  const int lane = pt_lane(), wave = (int)(threadIdx.x >> 6), nw = (int)(blockDim.x >> 6);
+  typedef uint16_t StackT;
+  StackT* stack = (StackT*)(lds_raw + (size_t)wave * PT_WAVE_STACK_BYTES(true, StackT, stack_depth));
+  const uint32_t n = PRIMARY ? n_primary : *q.count;
+  const uint32_t total_chunks = (uint32_t)(((unsigned long long)n + PT_WAVE - 1) / PT_WAVE);
+  uint32_t n_wg = total_chunks / (uint32_t)(PT_BOUNCE_MIN_CHUNKS * nw);
+  n_wg = n_wg < 1u ? 1u : (n_wg > gridDim.x ? gridDim.x : n_wg);
+  if (blockIdx.x >= n_wg) return; /* workgroup-uniform */
+  if (threadIdx.x == 0) { lds_chunk_ctr = 0u; lds_done = 0u; }
+  if (threadIdx.x < PT_POOL_BINS) lds_out[threadIdx.x] = (PT_POOL_NO_BLOCK << 12) | (uint32_t)PT_POOL_BLOCK; /* "full": the first push brings a block */
+  const PtSceneView sv = pt_scene_view<MODE, true, StackT>(sc, lds_raw, stack_depth); /* ends with the workgroup's only barrier */
+  uint2 (*pool)[128] = (uint2 (*)[128])(lds_raw + pool_off) + (size_t)wave * PT_N_SHADE_CAT;
+  uint32_t cnt[PT_N_SHADE_CAT];
+#pragma unroll
+  for (int k = 0; k < PT_N_SHADE_CAT; ++k) cnt[k] = 0u;
+  constexpr bool TAIL = PT_TAIL_CUT > 0 && !PRIMARY; /* camera rays walk as a packet (pt_trace_packet) and finish together */
+  constexpr bool TAIL_UV = TAIL && MODE == PT_MODE_ARRAY;
+  uint4* my_susp = susp + ((size_t)blockIdx.x * nw + wave) * (PT_WAVE * 3);
+  uint32_t n_susp = 0; /* wave-uniform */
+  bool more = true;    /* wave-uniform: the workgroup's share of the queue is not exhausted */
+  unsigned long long c_nodes = 0, c_prims = 0, c_floor = 0, c_seg = 0, c_filter[2] = {0, 0}; /* COUNT: as in k_trace */
+  /* the next chunk of the workgroup's share (runs of PT_POOL_RUN consecutive chunks, dealt round-robin, as in k_shade_pool) */
+  uint32_t pending = 0u; /* wave-uniform */
+#define PT_BOUNCE_TAKE() do { \
+    uint32_t unit_ = 0u; \
+    if (lane == 0) unit_ = __hip_atomic_fetch_add(&lds_chunk_ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); \
+    unit_ = (uint32_t)__builtin_amdgcn_readfirstlane((int)unit_); \
+    pending = (unit_ / PT_POOL_RUN) * (n_wg * PT_POOL_RUN) + blockIdx.x * PT_POOL_RUN + (unit_ % PT_POOL_RUN); \
+    if (PT_BOUNCE_PREFETCH && !PRIMARY && pending < total_chunks) { \
+      const uint32_t pi_ = pending * PT_WAVE + (uint32_t)lane; \
+      if (pi_ < n) (void)*(volatile const uint32_t*)(q.ray + pi_); \
+    } \
+  } while (0)
+  if (PT_BOUNCE_PREFETCH) PT_BOUNCE_TAKE();
+  for (;;) {
+    const bool input_left = more || n_susp > 0;
+    /* the fullest pool that holds a whole step; once nothing is left to walk, the fullest pool */
+    int c = -1;
+    uint32_t best = input_left ? (uint32_t)(PT_WAVE - 1) : 0u;
+#pragma unroll
+    for (int k = 0; k < PT_N_SHADE_CAT; ++k)
+      if (cnt[k] > best) { best = cnt[k]; c = k; }
+    if (c >= 0) {
+      const uint32_t take = best < (uint32_t)PT_WAVE ? best : (uint32_t)PT_WAVE;
+      const uint32_t start = best - take;
+      const bool live = (uint32_t)lane < take;
+      uint32_t i = 0u;
+      int sl = -1;
+      PtShadeOut so;
+      so.keep = false;
+#define PT_POOL_STEP(K, ...)                                                                                               \
+  case K: {                                                                                                                \
+    cnt[K] = start;                                                                                                        \
+    if (live) {                                                                                                            \
+      const uint2 e = pool[K][start + lane];                                                                               \
+      i = e.x;                                                                                                             \
+      sl = (int)e.y;                                                                                                       \
+    }                                                                                                                      \
+    pt_shade_entry<EMIT, PRIMARY, K>(sc, q, hits, contrib, alpha, bounce, last_bounce, g, i, live, so, ##__VA_ARGS__);    \
+  } break;
+      switch (c) {
+        PT_POOL_STEP(PT_CAT_MISS)
+        PT_POOL_STEP(PT_CAT_LAMBERT_SOLID, sl)
+        PT_POOL_STEP(PT_CAT_LAMBERT_CHECKER, sl)
+        PT_POOL_STEP(PT_CAT_METAL, sl)
+        PT_POOL_STEP(PT_CAT_DIELECTRIC, sl)
+        default: break;
+      }
+#undef PT_POOL_STEP
+      if (c != PT_CAT_MISS && !last_bounce) pt_pool_push<EMIT>(sc, out, so, lds_out);
+      continue;
+    }
+    if (!input_left) break;
+    /* walk: 64 parked rays once enough have gathered (or nothing else is left), else the next chunk of the share */
+    bool resume = false, valid = false;
+    uint32_t i = 0;
+    uint4 parked = make_uint4(0, 0, 0, 0), parked_uv = make_uint4(0, 0, 0, 0);
+    if (TAIL && (n_susp > (uint32_t)(PT_WAVE - PT_TAIL_CUT) || (!more && n_susp > 0))) {
+      resume = true;
+      valid = (uint32_t)lane < n_susp;
+      if (valid) parked = my_susp[lane];
+      if (TAIL_UV && valid) parked_uv = my_susp[PT_WAVE + lane];
+      i = parked.x;
+      n_susp = 0;
+    } else {
+      if (!PT_BOUNCE_PREFETCH) PT_BOUNCE_TAKE();
+      const uint32_t unit = pending;
+      if (PT_BOUNCE_PREFETCH && unit < total_chunks) PT_BOUNCE_TAKE();
+      more = unit < total_chunks;
+      if (more) {
+        i = unit * PT_WAVE + (uint32_t)lane;
+        valid = i < n;
+      }
+    }
+    V3 o = v3(0.0, 0.0, 0.0), d = v3(0.0, 0.0, -1.0); /* P3.origin */
+    if (valid) {
+      if (PRIMARY) {
+        const PtPrimarySample ps = pt_primary_decode(g, i);
+        valid = ps.valid;
+        if (valid) d = pt_primary_dir(sc, g, ps, alpha);
+      } else {
+        pt_q_load_ray(q, i, o, d);
+        if (pt_is_hole(d.x)) { /* never parked, so never seen on resume */
+          valid = false;
+          o = v3(0.0, 0.0, 0.0);
+          d = v3(0.0, 0.0, -1.0);
+        }
+      }
+    }
+    if (COUNT && valid && !resume) c_seg++;
+    PtTailCtl tc;
+    tc.min_active = (TAIL && more) ? PT_TAIL_CUT : 0; /* the last chunks of a wave run to completion */
+    tc.resume = resume && valid;
+    tc.node = parked.y & 0xffffu;
+    tc.slot = (int)(parked.y >> 16) == 0xffff ? -1 : (int)(parked.y >> 16);
+    tc.t = __hiloint2double((int)parked.w, (int)parked.z);
+    tc.u = __hiloint2double((int)parked_uv.y, (int)parked_uv.x);
+    tc.v = __hiloint2double((int)parked_uv.w, (int)parked_uv.z);
+    tc.unfinished = false;
+    PtTraceResult r;
+    if (PRIMARY) r = pt_trace_packet<MODE, COUNT, true, true>(sc, sv, (uint32_t*)stack, valid, o, d, c_nodes, c_prims, c_floor, c_filter);
+    else r = pt_trace_ray<MODE, COUNT, false, StackT, true>(sc, sv, stack, o, d, c_nodes, c_prims, c_floor, valid, TAIL ? &tc : nullptr, c_filter);
+    const bool park = TAIL && tc.unfinished;
+    const bool done = valid && !park;
+    int cat = PT_CAT_NONE;
+    if (done) {
+      /* the hit distance (and a triangle's barycentrics) reach the shade step through memory -- this wave's own L1 / L2
+       * lines; the slot travels in the pool entry */
+      if (MODE == PT_MODE_ARRAY && sc.has_triangles) hits.tuv[i] = make_double4(r.t, r.u, r.v, 0.0);
+      else hits.t[i] = r.t;
+      cat = r.slot < 0 ? PT_CAT_MISS : (int)sc.slot_cat[r.slot];
+    }
+#pragma unroll
+    for (int k = 0; k < PT_N_SHADE_CAT; ++k) {
+      const unsigned long long m = __ballot(cat == k);
+      if (cat == k) pool[k][cnt[k] + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = make_uint2(i, (uint32_t)r.slot);
+      cnt[k] += (uint32_t)__popcll(m);
+    }
+    if (TAIL) {
+      const unsigned long long pm = __ballot(park);
+      if (pm != 0) {
+        if (park) {
+          const uint32_t k = n_susp + (uint32_t)__popcll(pm & ((1ull << lane) - 1ull));
+          my_susp[k] = make_uint4(i, tc.node | ((uint32_t)(r.slot < 0 ? 0xffff : r.slot) << 16),
+                                  (uint32_t)__double2loint(r.t), (uint32_t)__double2hiint(r.t));
+          if (TAIL_UV)
+            my_susp[PT_WAVE + k] = make_uint4((uint32_t)__double2loint(r.u), (uint32_t)__double2hiint(r.u), (uint32_t)__double2loint(r.v), (uint32_t)__double2hiint(r.v));
+        }
+        n_susp += (uint32_t)__popcll(pm);
+      }
+    }
+    /* this wave's own stores (hit records, parked states, pool entries) before its own later loads of them: program order
+     * is enough for that (one wave's vector memory instructions reach the L1 / L2 in order), the compiler must not move them */
+#if PT_BOUNCE_FENCE_WG
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+#else
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#endif
+  }
+#undef PT_BOUNCE_TAKE
+  if (COUNT) {
+    c_nodes = pt_wave_sum(c_nodes);
+    c_prims = pt_wave_sum(c_prims);
+    c_floor = pt_wave_sum(c_floor);
+    c_seg = pt_wave_sum(c_seg);
+    c_filter[0] = pt_wave_sum(c_filter[0]);
+    c_filter[1] = pt_wave_sum(c_filter[1]);
+    if (lane == 0) {
+      atomicAdd(&counters->nodes, c_nodes);
+      atomicAdd(&counters->prims, c_prims);
+      atomicAdd(&counters->floor, c_floor);
+      atomicAdd(&counters->segments, c_seg);
+      atomicAdd(&counters->undecided, c_filter[0]);
+      atomicAdd(&counters->fallback_steps, c_filter[1]);
+    }
+  }
+  if (last_bounce) return;
+  /* the workgroup's last wave marks what is left of its blocks as holes */
+  uint32_t fin = 0u;
+  if (lane == 0) fin = __hip_atomic_fetch_add(&lds_done, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
+  fin = (uint32_t)__builtin_amdgcn_readfirstlane((int)fin);
+  if (fin != (uint32_t)(nw - 1)) return;
   for (int b = 0; b < PT_POOL_BINS; ++b) {
     const uint32_t st = __hip_atomic_load(lds_out + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     const uint32_t blk = st >> 12, pos = st & 0xfffu;

@@ -124,16 +124,30 @@ for k in kernels:
 json.dump(out, open(os.path.join(prof, f"{tag}_sq.json"), "w"), indent=1)
 
 
-# ---- the dominant kernel's entry for bench.py: k_trace / k_trace_stream instantiations with COUNT = false
+# ---- the dominant kernel's entry for bench.py: k_bounce (one launch per bounce, LDS-resident scenes) where it ran, else the
+# k_trace / k_trace_stream instantiations; COUNT = false (the counting renders are untimed)
+def targs_of(k):
+    return [t.strip() for t in k[k.index("<") + 1:k.rindex(">")].split(",")]
+
+
 def is_timed_trace(k):
-    if not k.startswith(("k_trace<", "k_trace_stream<")):
+    if not k.startswith(("k_trace<", "k_trace_stream<", "k_bounce<")):
         return False
-    targs = [t.strip() for t in k[k.index("<") + 1:k.rindex(">")].split(",")]
-    return targs[1] == "false"
+    return targs_of(k)[1] == "false"
+
+
+def is_primary(k):
+    if k.startswith("k_bounce<"):
+        return targs_of(k)[3] == "true"
+    if k.startswith("k_trace<"):
+        return targs_of(k)[2] == "true"
+    return False
 
 
 tr = {k: e for k, e in out["kernels"].items() if is_timed_trace(k) and e.get("launches")}
-sec = {k: e for k, e in tr.items() if k.startswith("k_trace_stream<") or [t.strip() for t in k[k.index("<") + 1:k.rindex(">")].split(",")][2] == "false"}
+if any(k.startswith("k_bounce<") for k in tr):
+    tr = {k: e for k, e in tr.items() if k.startswith("k_bounce<")}
+sec = {k: e for k, e in tr.items() if not is_primary(k)}
 ri_path = os.path.join(prof, "roofline_inputs.json")
 ri = json.load(open(ri_path)) if os.path.exists(ri_path) else {}
 if tr:
@@ -149,9 +163,9 @@ if tr:
     entry["counters_of"] = [k for k, e in out["kernels"].items() if e is dom][0]
     # time-weighted share of SIMD time the vector pipe issues, per stage (timed instantiations only): what bench.py turns
     # into the frame's vector-issue time (sum over stages of one-stream kernel time x this share)
-    for stage, pref in (("trace", ("k_trace<", "k_trace_stream<")), ("shade", ("k_shade<", "k_shade_pool<", "k_shade_cat<"))):
+    for stage, pref in (("trace", ("k_trace<", "k_trace_stream<")), ("shade", ("k_shade<", "k_shade_pool<", "k_shade_cat<")), ("bounce", ("k_bounce<",))):
         ks = [e for k, e in out["kernels"].items() if k.startswith(pref) and "one_stream" in e and e.get("valu_busy") is not None
-              and (stage != "trace" or is_timed_trace(k))]
+              and (stage == "shade" or is_timed_trace(k))]
         tot = sum(e["one_stream"]["total_ms"] for e in ks)
         if tot > 0:
             entry[f"valu_busy_{stage}_time_weighted"] = sum(e["valu_busy"] * e["one_stream"]["total_ms"] for e in ks) / tot
@@ -164,7 +178,7 @@ if tr:
         if acc_per_step and acc_total:
             frames = acc_total / acc_per_step
             def timed(k):
-                if k.startswith(("k_trace<", "k_trace_stream<")):
+                if k.startswith(("k_trace<", "k_trace_stream<", "k_bounce<")):
                     return is_timed_trace(k)
                 return k.startswith(("k_shade", "k_accum", "k_film", "k_classify"))
             tot = sum(e.get("hbm_bytes_per_launch", 0.0) * e["launches"] for k, e in out["kernels"].items() if timed(k) and e.get("launches"))
@@ -172,7 +186,7 @@ if tr:
             entry["hbm_bytes_per_step"] = tot / frames
             entry["hbm_bytes_per_step_by_stage"] = {
                 st: sum(e.get("hbm_bytes_per_launch", 0.0) * e["launches"] for k, e in out["kernels"].items() if timed(k) and k.startswith(pref) and e.get("launches")) / frames
-                for st, pref in (("trace", ("k_trace",)), ("shade", ("k_shade", "k_classify")), ("accum", ("k_accum",)), ("film", ("k_film",)))}
+                for st, pref in (("bounce", ("k_bounce",)), ("trace", ("k_trace",)), ("shade", ("k_shade", "k_classify")), ("accum", ("k_accum",)), ("film", ("k_film",)))}
     except Exception as ex:  # a profile without the bench line still summarises
         entry["hbm_bytes_per_step_error"] = str(ex)
     ri[workload] = entry
