@@ -10,6 +10,8 @@
  *              (integrator.ml:30-66), background on a miss; survivors are compacted into the next queue
  *   accum    : per-pixel radiance sums in pass order
  *   film     : 3x3 binomial reconstruction + gamma (filter_kernel.ml, film_tile.ml, integrator.ml:114-128,152-154)
+ * Scenes whose tree fits LDS run trace + shade of a bounce as ONE kernel (k_bounce: a wave walks 64 rays, files them in
+ * per-category pools, shades a pool when it holds 64); scenes walked from HBM / L2 keep k_trace + k_shade_pool.
  *
  * Compiled with -ffp-contract=off; every fused multiply-add below is written out exactly where the
  * reference writes Float.fma / _mm256_fmadd_pd.  No MFMA: there is no dense contraction on this path.
@@ -27,22 +29,19 @@
 /* A queue entry is two records: the ray (what k_trace reads, densely) and the rest of the path's state (what only the shade
  * stage reads, entry by entry in the order its category pools dictate -- one 32-byte sector instead of five 8-byte fields in
  * five different sectors).  Both are multiples of 16 bytes: every access is a 16-byte load or store. */
-#ifndef PT_RAY_PAD
-#define PT_RAY_PAD 0
-#endif
-#if PT_RAY_PAD
-struct PtRayRec { double ox, oy, oz, dx, dy, dz, pad0, pad1; };      /* experiment: one 64-byte line per ray */
-#else
-struct PtRayRec { double ox, oy, oz, dx, dy, dz; };                  /* 48 B: ray origin, direction */
-#endif
+struct PtRayRec { double ox, oy, oz, dx, dy, dz; };                  /* 48 B: ray origin, direction (padded to one 64-byte line
+                                                                         per ray: shade +20 % -- partial-line writes) */
 struct PtPathRec { double ar, ag, ab; uint32_t id; int32_t offset; }; /* 32 B: attn0 (integrator.ml:30); slot in the batch's
                                                                          contribution buffer; sampler offset = gy*W + gx + pass*spp
                                                                          (integrator.ml:98) */
-struct PtEmitRec { double er, eg, eb, pad; };                         /* 32 B: emit0; only allocated / touched when the scene has emitters */
+struct PtEmitRec { double er, eg, eb, pad; };                         /* 32 B: emit0; scenes with emitters only */
+/* Scenes with emitters keep an entry's path state and its carried emission in ONE 64-byte line: `path` then holds
+ * {PtPathRec, PtEmitRec} pairs (entry i at path + 2 i).  The shade stage gathers an entry's records sparsely and memory moves
+ * 64-byte lines: two 32-byte records in two arrays cost two lines per segment (cornell: 315 B fetched per segment against 144
+ * of records), the pair costs one. */
 struct PtQueue {
   PtRayRec* ray;
   PtPathRec* path;
-  PtEmitRec* emit;
   uint32_t* count; /* number of live entries (device) */
 };
 
@@ -72,17 +71,17 @@ __device__ __forceinline__ void pt_q_load_ray(const PtQueue& q, uint32_t i, V3& 
   o = v3(a.x, a.y, b.x);
   d = v3(b.y, c.x, c.y);
 }
-__device__ __forceinline__ void pt_q_load_path(const PtQueue& q, uint32_t i, V3& attn, uint32_t& id, int& offset) {
-  const double2* r = (const double2*)(q.path + i);
+template <bool EMIT>
+__device__ __forceinline__ void pt_q_load_path(const PtQueue& q, uint32_t i, V3& attn, uint32_t& id, int& offset, V3& emit) {
+  const double2* r = (const double2*)(q.path + (EMIT ? 2 * (size_t)i : (size_t)i));
   const double2 a = r[0], b = r[1];
   attn = v3(a.x, a.y, b.x);
   id = (uint32_t)__double2loint(b.y);
   offset = __double2hiint(b.y);
-}
-__device__ __forceinline__ V3 pt_q_load_emit(const PtQueue& q, uint32_t i) {
-  const double2* r = (const double2*)(q.emit + i);
-  const double2 a = r[0], b = r[1];
-  return v3(a.x, a.y, b.x);
+  if (EMIT) {
+    const double2 c = r[2], e = r[3];
+    emit = v3(c.x, c.y, e.x);
+  }
 }
 __device__ __forceinline__ void pt_q_store_ray(const PtQueue& q, uint32_t i, V3 o, V3 d) {
   /* a real ray's NaN that happens to carry the hole payload (it can only come in through the caller's data: arithmetic
@@ -96,13 +95,12 @@ __device__ __forceinline__ void pt_q_store_ray(const PtQueue& q, uint32_t i, V3 
 template <bool EMIT>
 __device__ __forceinline__ void pt_q_store(const PtQueue& q, uint32_t i, V3 o, V3 d, V3 attn, V3 emit, uint32_t id, int offset) {
   pt_q_store_ray(q, i, o, d);
-  double2* r = (double2*)(q.path + i);
+  double2* r = (double2*)(q.path + (EMIT ? 2 * (size_t)i : (size_t)i));
   r[0] = make_double2(attn.x, attn.y);
   r[1] = make_double2(attn.z, __hiloint2double(offset, (int)id));
   if (EMIT) {
-    double2* e = (double2*)(q.emit + i);
-    e[0] = make_double2(emit.x, emit.y);
-    e[1] = make_double2(emit.z, 0.0);
+    r[2] = make_double2(emit.x, emit.y);
+    r[3] = make_double2(emit.z, 0.0);
   }
 }
 
@@ -2185,8 +2183,7 @@ __device__ __forceinline__ void pt_shade_entry(const PtSceneDev& sc, const PtQue
         offset = ps.offset;
       } else {
         pt_q_load_ray(q, i, o, d);
-        pt_q_load_path(q, i, attn0, id, offset);
-        if (EMIT) emit0 = pt_q_load_emit(q, i);
+        pt_q_load_path<EMIT>(q, i, attn0, id, offset, emit0);
       }
       const int slot = CAT == PT_CAT_MISS ? -1 : (known_slot != PT_SLOT_HOLE ? known_slot : hits.slot[i]);
       V3 result = v3(0, 0, 0);

@@ -364,6 +364,8 @@ def test_random_configs_raw_sums_bitwise(P, oracle, seed, monkeypatch):
     monkeypatch.setenv("PTX_TRACE_WGS", str(int(rng.integers(0, 4))))  # trace workgroups per CU (0 = as many as fit)
     monkeypatch.setenv("PTX_SHADE_WGS", str(int(rng.integers(0, 4))))  # pooled shade workgroups per CU (0 = by schedule)
     monkeypatch.setenv("PTX_BIN_KEY", str(int(rng.integers(0, 3))))  # survivors binned by octant / elevation / reaches-the-tree's-box
+    monkeypatch.setenv("PTX_FUSED", str(int(rng.integers(0, 3))))  # k_bounce for every bounce / all but the camera rays' / k_trace + shade kernels
+    monkeypatch.setenv("PTX_BOUNCE_THREADS", str(int(rng.choice([0, 64, 192, 512]))))  # k_bounce workgroup size (0 = 1024)
     o_scene = oracle.Scene(d.ptr, d)
     g_scene = P.Scene(d.ptr, 0, keepalive=d)
     c = o_scene.render(w, h, spp, depth, threads=8, want_raw=True)
@@ -391,6 +393,7 @@ def test_tail_cut_and_threaded_walk_under_small_grids(P, oracle, kind, block, wg
     for LDS: the same cut over the walk from HBM / L2 (32-bit node indices, barycentrics and the filter's copy of t restored
     on resume -- a stale copy passes boxes beyond the hit and shows up in nodes_tested only)."""
     torch = pytest.importorskip("torch")
+    monkeypatch.setenv("PTX_FUSED", "0")  # k_trace + k_shade_pool (k_bounce: test_bounce_kernel_against_the_oracle below)
     monkeypatch.setenv("PTX_TRACE_BLOCK", str(block))
     monkeypatch.setenv("PTX_TRACE_WGS", str(wgs))
     monkeypatch.setenv("PTX_STREAMS", "1")
@@ -405,6 +408,41 @@ def test_tail_cut_and_threaded_walk_under_small_grids(P, oracle, kind, block, wg
     assert np.array_equal(bits(raw.cpu().numpy()), bits(c["raw"]))
     for k in ("segments", "nodes_tested", "prims_tested", "floor_tested"):
         assert st[k] == c["counters"][k], k
+    g.close()
+
+
+@pytest.mark.parametrize("kind,fused,threads,wgs", [("shirley", 2, 0, 0), ("shirley", 2, 64, 4), ("shirley", 1, 256, 16), ("shirley_no_simd", 2, 128, 8),
+                                                     ("cornell", 2, 0, 0), ("cornell", 2, 64, 2), ("cornell", 1, 512, 3)])
+def test_bounce_kernel_against_the_oracle(P, oracle, kind, fused, threads, wgs, monkeypatch):
+    """k_bounce -- the default for scenes whose tree fits LDS: a bounce's walk and its pooled shade in ONE launch -- must be the
+    path that runs (ptx_stats counts its launches apart from k_trace / k_shade_pool) and give the oracle's raw sums and work
+    counters bit for bit.  Small workgroups and a handful of them give every wave hundreds of chunks: many rounds of parking
+    and resuming walks between shade steps, pools that fill in every order, the final drain, part-filled output blocks.
+    fused = 1 keeps the camera rays' bounce on k_trace + k_shade_pool."""
+    torch = pytest.importorskip("torch")
+    monkeypatch.setenv("PTX_FUSED", str(fused))
+    monkeypatch.setenv("PTX_BOUNCE_THREADS", str(threads))
+    monkeypatch.setenv("PTX_BOUNCE_WGS", str(wgs))
+    w, h, spp, depth = 384, 192, 6, 10
+    d = {"shirley": lambda: oracle.desc_shirley(w, h), "shirley_no_simd": lambda: oracle.desc_shirley(w, h, no_simd=True),
+         "cornell": lambda: oracle.desc_cornell(w, h)}[kind]()
+    c = oracle.Scene(d.ptr, d).render(w, h, spp, depth, threads=8, want_raw=True, count=True)
+    g = P.Scene(d.ptr, 0, keepalive=d)
+    assert g.stats()["traversal_in_lds"] == 1
+    raw = torch.zeros((h, w, 3), dtype=torch.float64, device="cuda:0")
+    for streams in ("1", "2"):
+        monkeypatch.setenv("PTX_STREAMS", streams)
+        for count in (True, False):
+            raw.zero_()
+            st = g.render_raw_device(P.render_params(w, h, spp, depth, count_work=count, time_kernels=True, passes_per_batch=2), raw.data_ptr())
+            assert np.array_equal(bits(raw.cpu().numpy()), bits(c["raw"])), (streams, count)
+            if count:
+                for k in ("segments", "nodes_tested", "prims_tested", "floor_tested"):
+                    assert st[k] == c["counters"][k], k
+            n_batches = (spp + 1) // 2
+            kl = st["kernel_launches"]
+            assert kl["bounce"] == n_batches * (depth if fused == 2 else depth - 1), kl
+            assert kl["trace"] == kl["shade"] == (0 if fused == 2 else n_batches), kl
     g.close()
 
 
