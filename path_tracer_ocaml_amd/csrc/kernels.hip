@@ -1000,7 +1000,7 @@ struct PtTailCtl {
   int slot;
   bool unfinished;  /* out: the ray is still walking */
 };
-template <int MODE, bool COUNT, bool ORIGIN_ZERO, typename StackT, bool SWZ = false>
+template <int MODE, bool COUNT, bool ORIGIN_ZERO, typename StackT, bool SWZ = false, bool DIV_LOOP = (PT_WALK_LOOP != 0)>
 __device__ __forceinline__ PtTraceResult pt_trace_ray(const PtSceneDev& sc, const PtSceneView& sv, StackT* stack,
                                                       V3 o, V3 d, unsigned long long& c_nodes,
                                                       unsigned long long& c_prims, unsigned long long& c_floor,
@@ -1019,12 +1019,14 @@ __device__ __forceinline__ PtTraceResult pt_trace_ray(const PtSceneDev& sc, cons
     if (tr.FILT) tr.update_t32(); /* the filter's copy of t: stale, it would pass boxes beyond the restored hit */
   }
   while (valid && (tr.walking || tr.leaf_n > 0)) {
-#if PT_WALK_LOOP
-    /* The node walk as ONE divergent loop: a lane stays in it while it wants node steps, so the lanes still walking are
-     * simply the loop's exec mask (no per-turn ballot of a `want` flag, no `continue`, no exit-reason bookkeeping: the
-     * first version of this loop spent ~19 of its ~80 instructions per turn on that).  Same rule as before: once fewer than
-     * PT_WALK_MIN lanes are walking and some lane holds a leaf, the pending packets are intersected first. */
-    if (tr.wants_node()) {
+    /* DIV_LOOP: the node walk as ONE divergent loop: a lane stays in it while it wants node steps, so the lanes still walking
+     * are simply the loop's exec mask (no per-turn ballot of a `want` flag, no `continue`, no exit-reason bookkeeping: the
+     * first version of this loop spent ~19 of its ~80 instructions per turn on that).  Same rule as below: once fewer than
+     * PT_WALK_MIN lanes are walking and some lane holds a leaf, the pending packets are intersected first.  Half the SCALAR
+     * instructions per turn: +3 % time in k_trace at 8 waves per SIMD (scalar issue is not what binds there), -1 % in k_bounce
+     * at 4 (with half the waves, a wave busy with scalar bookkeeping is more often the one the vector pipe is waiting for). */
+    if constexpr (DIV_LOOP) {
+     if (tr.wants_node()) {
       bool leaf_waiting = false; /* wave-uniform: a lane of this wave left the walk holding a leaf */
       for (;;) {
         if (COUNT && PT_DIAG == 1 && !ORIGIN_ZERO) PT_DIAG_WAVE_SLOTS(c_floor);
@@ -1033,8 +1035,8 @@ __device__ __forceinline__ PtTraceResult pt_trace_ray(const PtSceneDev& sc, cons
         if (!tr.wants_node()) break;
         if (leaf_waiting && (int)__popcll(__ballot(1)) < PT_WALK_MIN) break;
       }
-    }
-#else
+     }
+    } else {
     for (;;) {
       /* keep walking while enough lanes still want a node step; once fewer than PT_WALK_MIN do and some lane
        * already holds a leaf, intersect the pending packets first (the stragglers resume afterwards) */
@@ -1045,7 +1047,7 @@ __device__ __forceinline__ PtTraceResult pt_trace_ray(const PtSceneDev& sc, cons
       if (!tr.wants_node()) continue;
       tr.node_step(sv, stack, c_nodes, c_prims);
     }
-#endif
+    }
     if (tr.leaf_n > 0) tr.packet(sv, c_nodes, c_floor);
     /* nobody holds a leaf here: a safe place to stop.  The ballot sees the rays that are still walking (finished
      * lanes have left the loop), and every one of them sees the same count. */
@@ -2677,6 +2679,13 @@ __global__ __launch_bounds__(PT_POOL_THREADS, PT_SHADE_WAVES) void k_shade_pool(
 #ifndef PT_BOUNCE_THREADS
 #define PT_BOUNCE_THREADS 1024
 #endif
+#ifndef PT_BOUNCE_WAVES
+#define PT_BOUNCE_WAVES 4 /* waves per SIMD asked of the register allocator (PT_BOUNCE_THREADS / 256); 768 threads / 3 waves: +16 % */
+#endif
+#ifndef PT_BOUNCE_DIV_LOOP
+#define PT_BOUNCE_DIV_LOOP(MODE) ((MODE) == PT_MODE_SIMD) /* the walk phase's node loop as one divergent loop (pt_trace_ray DIV_LOOP):
+                                                              headline -0.7 ... -1.1 %, cornell (Array_leaf) +1 % */
+#endif
 #ifndef PT_BOUNCE_MIN_CHUNKS
 #define PT_BOUNCE_MIN_CHUNKS 2 /* chunks per wave below which fewer workgroups take part (k_shade_pool: 16 -- there a chunk is a few microseconds) */
 #endif
@@ -2687,7 +2696,7 @@ __global__ __launch_bounds__(PT_POOL_THREADS, PT_SHADE_WAVES) void k_shade_pool(
 #define PT_BOUNCE_FENCE_WG 0 /* 1: workgroup-scope fences (s_waitcnt vmcnt(0)) around the wave's own hit / parked records instead of wavefront scope */
 #endif
 template <int MODE, bool COUNT, bool EMIT, bool PRIMARY>
-__global__ __launch_bounds__(PT_BOUNCE_THREADS, 4) void k_bounce(PtSceneDev sc, PtQueue q, PtHits hits, PtQueue out, PtContrib contrib,
+__global__ __launch_bounds__(PT_BOUNCE_THREADS, PT_BOUNCE_WAVES) void k_bounce(PtSceneDev sc, PtQueue q, PtHits hits, PtQueue out, PtContrib contrib,
                                                                  const double* __restrict__ alpha, int bounce, int last_bounce, PtGenParams g,
                                                                  uint32_t n_primary, int stack_depth, uint32_t pool_off, uint4* susp,
                                                                  PtCounters* counters) {
@@ -2815,7 +2824,7 @@ __global__ __launch_bounds__(PT_BOUNCE_THREADS, 4) void k_bounce(PtSceneDev sc, 
     tc.unfinished = false;
     PtTraceResult r;
     if (PRIMARY) r = pt_trace_packet<MODE, COUNT, true, true>(sc, sv, (uint32_t*)stack, valid, o, d, c_nodes, c_prims, c_floor, c_filter);
-    else r = pt_trace_ray<MODE, COUNT, false, StackT, true>(sc, sv, stack, o, d, c_nodes, c_prims, c_floor, valid, TAIL ? &tc : nullptr, c_filter);
+    else r = pt_trace_ray<MODE, COUNT, false, StackT, true, PT_BOUNCE_DIV_LOOP(MODE)>(sc, sv, stack, o, d, c_nodes, c_prims, c_floor, valid, TAIL ? &tc : nullptr, c_filter);
     const bool park = TAIL && tc.unfinished;
     const bool done = valid && !park;
     int cat = PT_CAT_NONE;
