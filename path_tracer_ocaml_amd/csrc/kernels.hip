@@ -1448,6 +1448,9 @@ struct PtChunkFeed {
 #ifndef PT_TAIL_CUT
 #define PT_TAIL_CUT 16 /* 0 = off */
 #endif
+#ifndef PT_TRACE_DIV_LOOP
+#define PT_TRACE_DIV_LOOP(LDS_SCENE) (PT_WALK_LOOP != 0 || !(LDS_SCENE))
+#endif
 #ifndef PT_TRACE_DUAL
 #define PT_TRACE_DUAL 0 /* scenes walked from HBM / L2: 1 = two rays per lane (pt_trace_ray2), 0 = one */
 #endif
@@ -1675,7 +1678,9 @@ __global__ __launch_bounds__(PT_TRACE_BLOCK_OF(MODE, LDS_SCENE), (LDS_SCENE && M
       tc.v = __hiloint2double((int)parked_uv.w, (int)parked_uv.z);
       tc.unfinished = false;
       /* every lane goes in (wave-level ballots inside); lanes without a ray commit nothing */
-      const PtTraceResult r = pt_trace_ray<MODE, COUNT, PRIMARY, StackT, LDS_SCENE>(sc, sv, stack, o, d, c_nodes, c_prims, c_floor, valid, TAIL ? &tc : nullptr, c_filter);
+      /* (the node loop as one divergent loop where the kernel runs at 4 waves per SIMD: the walk from HBM / L2 -- ganesha-like
+       * frame 35.4 -> 33.6 ms; the LDS walk at 8 waves per SIMD loses 3 % with it) */
+      const PtTraceResult r = pt_trace_ray<MODE, COUNT, PRIMARY, StackT, LDS_SCENE, PT_TRACE_DIV_LOOP(LDS_SCENE)>(sc, sv, stack, o, d, c_nodes, c_prims, c_floor, valid, TAIL ? &tc : nullptr, c_filter);
       if (COUNT && PT_DIAG == 2 && !PRIMARY && valid) {
         unsigned long long m = c_nodes - diag_n0;
         for (int off = 32; off > 0; off >>= 1) {
