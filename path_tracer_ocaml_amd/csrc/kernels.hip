@@ -425,6 +425,9 @@ __device__ __forceinline__ uint32_t pt_stack_pop(const PtThreadTag*, int) { retu
 #ifndef PT_LEAF_PREFETCH
 #define PT_LEAF_PREFETCH 1 /* triangle-only scenes walked from HBM / L2: request triangle k + 1 before testing triangle k */
 #endif
+#ifndef PT_LEAN_FALLBACK
+#define PT_LEAN_FALLBACK 1
+#endif
 #ifndef PT_WALK_LOOP
 #define PT_WALK_LOOP 0 /* 0: wave-level loop with a `want` ballot per turn; 1: the node walk as one divergent loop (fewer scalar
                           instructions per turn, but the kernel is bound by VECTOR issue: measured 3 % slower) */
@@ -583,6 +586,22 @@ struct PtTraverser {
         const float u = __builtin_fminf(b, t32) - __builtin_fmaxf(a, 0.0f);
         const float m2 = __builtin_fmaf(__uint_as_float(lk.y), k2, c2);
         hit = u >= m2;
+#if PT_LEAN_FALLBACK
+        if (!COUNT) {
+          /* one divergent branch, no wave-uniform pre-check: two scalar instructions per visit instead of five (at 4 waves per
+           * SIMD the scalar instructions of a visit -- 27 against 22 vector ones -- are no longer free) */
+          if (active && !(__builtin_fabsf(u) >= m2)) {
+            const PtNode* np = sv.nodes + (nd - sv.swz_root) / PT_SWZ_NODE_BYTES;
+            double qx = d.x, qy = d.y, qz = d.z;
+            asm volatile("" : "+v"(qx), "+v"(qy), "+v"(qz));
+            const V3 inv64 = v3(1.0 / qx, 1.0 / qy, 1.0 / qz);
+            hit = (!(pt_isfinite(inv64.x) && pt_isfinite(inv64.y) && pt_isfinite(inv64.z)))
+                      ? pt_slab_hit_exact(np->mn, o, inv64, t_min, r.t)
+                      : pt_slab_hit_fast<ORIGIN_ZERO>(np->mn, o, inv64, t_min, r.t);
+          }
+          return hit;
+        }
+#endif
         if (__builtin_amdgcn_fcmpf(__builtin_fabsf(u), active ? m2 : 0.0f, 12) != 0) { /* as below */
           const bool undecided = active && !(__builtin_fabsf(u) >= m2);
           if (COUNT) {
@@ -642,6 +661,21 @@ struct PtTraverser {
        * m2 is twice the error bound */
       /* (the wave mask straight from the comparison -- predicate 12 = unordered or less than; a ballot of the boolean that the
        * branch below also uses makes the compiler materialise it per lane first) */
+#if PT_LEAN_FALLBACK
+      if (!COUNT) { /* as in the layout-3 branch above: one divergent branch */
+        if (active && !(__builtin_fabsf(u) >= m2)) {
+          const PtNode* np = sv.nodes + (SWZ ? nd / PT_SWZ_NODE_BYTES
+                                             : ((nd & PT_TOP_FLAG) ? *(const uint32_t*)(sv.top + (nd & (PT_TOP_FLAG - 1u)) + 48) : nd));
+          double qx = d.x, qy = d.y, qz = d.z;
+          asm volatile("" : "+v"(qx), "+v"(qy), "+v"(qz));
+          const V3 inv64 = v3(1.0 / qx, 1.0 / qy, 1.0 / qz);
+          hit = (!(pt_isfinite(inv64.x) && pt_isfinite(inv64.y) && pt_isfinite(inv64.z)))
+                    ? pt_slab_hit_exact(np->mn, o, inv64, t_min, r.t)
+                    : pt_slab_hit_fast<ORIGIN_ZERO>(np->mn, o, inv64, t_min, r.t);
+        }
+        return hit;
+      }
+#endif
       if (__builtin_amdgcn_fcmpf(__builtin_fabsf(u), active ? m2 : 0.0f, 12) != 0) {
         const bool undecided = active && !(__builtin_fabsf(u) >= m2);
         if (COUNT) {
