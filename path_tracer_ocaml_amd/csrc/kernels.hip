@@ -1912,14 +1912,38 @@ __device__ __forceinline__ Quat pt_quat_conj(Quat q) {
   return c;
 }
 
+/* What a segment needs of its slot's shading record (PtShadeRec), in registers: every address is known the moment the segment
+ * starts (queue index and hit slot), so everything is requested in one round (pt_shade_entry) instead of field by field where
+ * the code needs it.  Which fields are read is fixed by the category when the kernel is specialised for one. */
+struct PtMatRegs {
+  int kind, tex_kind, tex_w, tex_h;
+  double index;
+  V3 even, odd, emit;
+};
+template <int CAT, bool EMIT>
+__device__ __forceinline__ PtMatRegs pt_mat_load(const PtShadeRec* m) {
+  PtMatRegs r;
+  r.kind = (CAT == PT_CAT_LAMBERT_SOLID || CAT == PT_CAT_LAMBERT_CHECKER) ? 0 : (CAT == PT_CAT_METAL ? 1 : (CAT == PT_CAT_DIELECTRIC ? 2 : m->kind));
+  r.tex_kind = CAT == PT_CAT_LAMBERT_SOLID ? 0 : (CAT == PT_CAT_LAMBERT_CHECKER ? 1 : (CAT == PT_CAT_DIELECTRIC ? 0 : m->tex_kind));
+  const bool tex = CAT != PT_CAT_DIELECTRIC;
+  const bool checker = CAT != PT_CAT_DIELECTRIC && CAT != PT_CAT_LAMBERT_SOLID;
+  r.tex_w = checker ? m->tex_w : 1;
+  r.tex_h = checker ? m->tex_h : 1;
+  r.index = (CAT == PT_CAT_DIELECTRIC || CAT == PT_CAT_NONE) ? m->index : 1.0;
+  r.even = tex ? v3(m->even[0], m->even[1], m->even[2]) : v3(0.0, 0.0, 0.0);
+  r.odd = checker ? v3(m->odd[0], m->odd[1], m->odd[2]) : v3(0.0, 0.0, 0.0);
+  r.emit = EMIT ? v3(m->emit[0], m->emit[1], m->emit[2]) : v3(0.0, 0.0, 0.0);
+  return r;
+}
+
 /* Texture.eval (texture.ml:16-31) */
-__device__ __forceinline__ V3 pt_texture_eval(const PtShadeRec& t, double u, double v) {
-  if (t.tex_kind == 0) return v3(t.even[0], t.even[1], t.even[2]);
+__device__ __forceinline__ V3 pt_texture_eval(const PtMatRegs& t, double u, double v) {
+  if (t.tex_kind == 0) return t.even;
   const double width = (double)(t.tex_w - 1), height = (double)(t.tex_h - 1);
   const double xp = u * width, yp = v * height;
   const long long px = ((long long)xp) & 1, py = ((long long)yp) & 1; /* Float.to_int a land 1 */
-  if (px == py) return v3(t.even[0], t.even[1], t.even[2]);
-  return v3(t.odd[0], t.odd[1], t.odd[2]);
+  if (px == py) return t.even;
+  return t.odd;
 }
 
 /* schlick_reflectance (material.ml:16-20) */
@@ -1946,27 +1970,45 @@ struct PtSurface {
   V3 omega_i;       /* Shader_space.omega_i */
   double tu, tv;    /* Texture.Coord */
   bool hit_front;
-  const PtShadeRec* m; /* the slot's material and texture: read field by field, never copied (96 B would go to scratch) */
 };
+/* geometry of the hit slot requested together with the rest of the segment's inputs (pt_shade_entry): the sphere's record on
+ * scenes without triangles; with triangles the slot's kind, which decides what to fetch in a second round */
+struct PtSlotGeom {
+  double cx, cy, cz;
+  int kind; /* PT_SLOT_* */
+};
+/* (the photon passes' form: one ray at a time, nothing to batch the loads with) */
+__device__ __forceinline__ PtSlotGeom pt_slot_geom(const PtSceneDev& sc, int slot) {
+  PtSlotGeom g;
+  g.cx = g.cy = g.cz = 0.0;
+  g.kind = sc.has_triangles ? (int)sc.slot_kind[slot] : PT_SLOT_SPHERE;
+  if (!sc.has_triangles) {
+    const double* s = sc.sph + (size_t)slot * 4;
+    g.cx = s[0];
+    g.cy = s[1];
+    g.cz = s[2];
+  }
+  return g;
+}
 /* CAT: the shading category when the caller knows it at compile time (per-category shade kernels), PT_CAT_NONE when it
  * has to be read from the slot's record */
 template <int CAT = PT_CAT_NONE>
 __device__ __forceinline__ PtSurface pt_surface_hit(const PtSceneDev& sc, V3 o, V3 d, int slot, double t_hit, double bu,
-                                                    double bv) {
+                                                    double bv, const PtMatRegs& m, const PtSlotGeom& geom) {
   const double pi = 3.14159265358979323846;
   PtSurface sf;
-  sf.m = sc.slot_shade + slot;
   sf.tu = 0.0;
   sf.tv = 0.0;
-  const PtShadeRec& m = *sf.m;
   /* tex_coord feeds Texture.eval only, and only a checker reads it */
   const bool need_uv = CAT == PT_CAT_LAMBERT_SOLID || CAT == PT_CAT_DIELECTRIC ? false
                        : (CAT == PT_CAT_LAMBERT_CHECKER ? true : ((m.kind != 2) && (m.tex_kind != 0)));
-  /* (a scene without triangles: no load of the slot's kind in front of the loads of its geometry) */
-  if (!sc.has_triangles || sc.slot_kind[slot] == PT_SLOT_SPHERE) {
+  if (geom.kind == PT_SLOT_SPHERE) {
     /* Sphere.hit (sphere.ml:56-69) */
-    const double* s = sc.sph + (size_t)slot * 4;
-    const V3 center = v3(s[0], s[1], s[2]);
+    V3 center = v3(geom.cx, geom.cy, geom.cz);
+    if (sc.has_triangles) { /* (mixed scenes learn the slot's kind in the first round and fetch its geometry in a second) */
+      const double* s = sc.sph + (size_t)slot * 4;
+      center = v3(s[0], s[1], s[2]);
+    }
     sf.point = v3_add(o, v3_scale(d, t_hit)); /* Ray.point_at, ray.ml:15 */
     V3 normal = v3_normalize(v3_sub(sf.point, center));
     sf.hit_front = v3_dot(d, normal) < 0.0;
@@ -2005,8 +2047,7 @@ struct PtScatter {
   V3 attenuation, wo;
 };
 template <int CAT = PT_CAT_NONE>
-__device__ __forceinline__ PtScatter pt_material_scatter(const PtSceneDev& sc, const PtSurface& sf, double su) {
-  const PtShadeRec& m = *sf.m;
+__device__ __forceinline__ PtScatter pt_material_scatter(const PtSceneDev& sc, const PtSurface& sf, const PtMatRegs& m, double su) {
   const V3 omega_i = sf.omega_i;
   PtScatter r;
   r.attenuation = v3(1.0, 1.0, 1.0);
@@ -2233,26 +2274,37 @@ __device__ __forceinline__ void pt_shade_entry(const PtSceneDev& sc, const PtQue
         /* None -> add_mul emit0 attn0 (background ray), integrator.ml:36 */
         result = v3_fma(attn0, pt_background(sc, d), emit0);
       } else {
+        /* the rest of the segment's inputs, requested in the same round as the queue records above (PtMatRegs): the hit
+         * distance, the slot's shading record, and its geometry (or, with triangles in the scene, its kind) */
         double t_hit, bu = 0.0, bv = 0.0;
+        PtSlotGeom geom;
+        geom.cx = geom.cy = geom.cz = 0.0;
+        geom.kind = PT_SLOT_SPHERE;
         if (sc.has_triangles) { /* one 32-byte record (PtHits) */
           const double2* hp = (const double2*)(hits.tuv + i);
           const double2 h0 = hp[0], h1 = hp[1];
           t_hit = h0.x;
           bu = h0.y;
           bv = h1.x;
+          geom.kind = (int)sc.slot_kind[slot];
         } else {
           t_hit = hits.t[i];
+          const double2* sp = (const double2*)(sc.sph + (size_t)slot * 4);
+          const double2 s0 = sp[0], s1 = sp[1];
+          geom.cx = s0.x;
+          geom.cy = s0.y;
+          geom.cz = s1.x;
         }
-        const bool is_tri = sc.has_triangles && sc.slot_kind[slot] != PT_SLOT_SPHERE;
-        const PtSurface sf = pt_surface_hit<CAT>(sc, o, d, slot, t_hit, is_tri ? bu : 0.0, is_tri ? bv : 0.0);
-        const PtShadeRec& m = *sf.m;
+        const PtMatRegs m = pt_mat_load<CAT, EMIT>(sc.slot_shade + slot);
+        const bool is_tri = geom.kind != PT_SLOT_SPHERE;
+        const PtSurface sf = pt_surface_hit<CAT>(sc, o, d, slot, t_hit, is_tri ? bu : 0.0, is_tri ? bv : 0.0, m, geom);
         const V3 point = sf.point;
         const Quat rot_inv = pt_quat_conj(sf.rot);
-        const V3 emit = EMIT ? v3(m.emit[0], m.emit[1], m.emit[2]) : v3(0.0, 0.0, 0.0);
+        const V3 emit = m.emit;
         /* take_2d (), integrator.ml:20-28,39: dims 2+2k, 3+2k for the k-th hit */
         const double su = pt_lds_get(alpha, offset, 2 + 2 * bounce);
         const double sv = pt_lds_get(alpha, offset, 3 + 2 * bounce);
-        const PtScatter scat = pt_material_scatter<CAT>(sc, sf, su);
+        const PtScatter scat = pt_material_scatter<CAT>(sc, sf, m, su);
         const int sc_kind = scat.kind;
         V3 attenuation = scat.attenuation;
         V3 wo = scat.wo;
