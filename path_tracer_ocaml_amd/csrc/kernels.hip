@@ -2780,9 +2780,6 @@ __global__ __launch_bounds__(PT_POOL_THREADS, PT_SHADE_WAVES) void k_shade_pool(
 #ifndef PT_BOUNCE_MIN_CHUNKS
 #define PT_BOUNCE_MIN_CHUNKS 2 /* chunks per wave below which fewer workgroups take part (k_shade_pool: 16 -- there a chunk is a few microseconds) */
 #endif
-#ifndef PT_BOUNCE_PREFETCH
-#define PT_BOUNCE_PREFETCH 0 /* a wave holds the chunk it will walk NEXT and has touched its ray records (one dword per lane covers every line) */
-#endif
 #ifndef PT_BOUNCE_FENCE_WG
 #define PT_BOUNCE_FENCE_WG 0 /* 1: workgroup-scope fences (s_waitcnt vmcnt(0)) around the wave's own hit / parked records instead of wavefront scope */
 #endif
@@ -2815,19 +2812,6 @@ __global__ __launch_bounds__(PT_BOUNCE_THREADS, PT_BOUNCE_WAVES) void k_bounce(P
   uint32_t n_susp = 0; /* wave-uniform */
   bool more = true;    /* wave-uniform: the workgroup's share of the queue is not exhausted */
   unsigned long long c_nodes = 0, c_prims = 0, c_floor = 0, c_seg = 0, c_filter[2] = {0, 0}; /* COUNT: as in k_trace */
-  /* the next chunk of the workgroup's share (runs of PT_POOL_RUN consecutive chunks, dealt round-robin, as in k_shade_pool) */
-  uint32_t pending = 0u; /* wave-uniform */
-#define PT_BOUNCE_TAKE() do { \
-    uint32_t unit_ = 0u; \
-    if (lane == 0) unit_ = __hip_atomic_fetch_add(&lds_chunk_ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); \
-    unit_ = (uint32_t)__builtin_amdgcn_readfirstlane((int)unit_); \
-    pending = (unit_ / PT_POOL_RUN) * (n_wg * PT_POOL_RUN) + blockIdx.x * PT_POOL_RUN + (unit_ % PT_POOL_RUN); \
-    if (PT_BOUNCE_PREFETCH && !PRIMARY && pending < total_chunks) { \
-      const uint32_t pi_ = pending * PT_WAVE + (uint32_t)lane; \
-      if (pi_ < n) (void)*(volatile const uint32_t*)(q.ray + pi_); \
-    } \
-  } while (0)
-  if (PT_BOUNCE_PREFETCH) PT_BOUNCE_TAKE();
   for (;;) {
     const bool input_left = more || n_susp > 0;
     /* the fullest pool that holds a whole step; once nothing is left to walk, the fullest pool */
@@ -2879,9 +2863,12 @@ __global__ __launch_bounds__(PT_BOUNCE_THREADS, PT_BOUNCE_WAVES) void k_bounce(P
       i = parked.x;
       n_susp = 0;
     } else {
-      if (!PT_BOUNCE_PREFETCH) PT_BOUNCE_TAKE();
-      const uint32_t unit = pending;
-      if (PT_BOUNCE_PREFETCH && unit < total_chunks) PT_BOUNCE_TAKE();
+      /* the next chunk of the workgroup's share (runs of PT_POOL_RUN consecutive chunks, dealt round-robin, as in k_shade_pool;
+       * taking a chunk one turn ahead and touching its ray records cost 2 %: the lines arrive in time anyway) */
+      uint32_t unit = 0u;
+      if (lane == 0) unit = __hip_atomic_fetch_add(&lds_chunk_ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      unit = (uint32_t)__builtin_amdgcn_readfirstlane((int)unit);
+      unit = (unit / PT_POOL_RUN) * (n_wg * PT_POOL_RUN) + blockIdx.x * PT_POOL_RUN + (unit % PT_POOL_RUN);
       more = unit < total_chunks;
       if (more) {
         i = unit * PT_WAVE + (uint32_t)lane;
@@ -2955,7 +2942,6 @@ __global__ __launch_bounds__(PT_BOUNCE_THREADS, PT_BOUNCE_WAVES) void k_bounce(P
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #endif
   }
-#undef PT_BOUNCE_TAKE
   if (COUNT) {
     c_nodes = pt_wave_sum(c_nodes);
     c_prims = pt_wave_sum(c_prims);
