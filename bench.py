@@ -281,8 +281,10 @@ def main():
     scene = P.Scene(hs.ptr, local_dev, keepalive=hs)
     sstats = scene.stats()
 
+    # the timed steps are QUEUED (PTX_RENDER_ASYNC, ptx_film_resolve_banded_queue): frame k + 1 is being launched while frame k's
+    # bands travel and its film runs; the fence around the K steps waits for all of it.  No event timing in the timed region.
     params = P.render_params(w, h, spp, depth, band_rows=D.BAND_ROWS, band_first=rank, band_step=world,
-                             time_kernels=True, passes_per_batch=args.passes_per_batch)
+                             passes_per_batch=args.passes_per_batch, asynchronous=True)
     # every buffer of the step is allocated here, once: each rank renders into its send buffer (rank 0 into slice 0
     # of the receive buffer), the peers' bands arrive in place, and the film kernel reads the banded layout as it is
     bg = D.BandGather(h, w, rank, world, dev)
@@ -295,7 +297,7 @@ def main():
         gathered = bg.gather()
         if rank == 0:
             P.film_resolve_banded_device(local_dev, w, h, spp, gathered.data_ptr(), world, D.BAND_ROWS, bg.pad_rows,
-                                         rgb.data_ptr(), stream)
+                                         rgb.data_ptr(), stream, wait=False)
         return st
 
     def fence():

@@ -146,8 +146,13 @@ typedef struct ptx_render_params {
    * interleaved row bands).  0 or 1 = the scene's own device only.  Devices used: the scene's, then the following
    * ordinals (mod ptx_device_count()); replicas of the scene are made on first use and kept with the handle. */
   int32_t n_gpus;
-  int32_t reserved;
+  /* PTX_RENDER_ASYNC (ptx_render_raw_device only): return as soon as the frame is QUEUED on `stream` -- the caller's next use
+   * of the buffer must be ordered after it on that stream (as a following ptx_* call or a collective on it is), or wait for
+   * the stream.  `stats` then carries no timings or counters; count_work / time_kernels renders always wait.  For hosts
+   * that pipeline frames (one rank of a multi-GPU job: the next frame is queued while this one's bands travel). */
+  int32_t flags;
 } ptx_render_params;
+#define PTX_RENDER_ASYNC 1
 
 #define PTX_KERNEL_GENERATE 0
 #define PTX_KERNEL_TRACE 1
@@ -284,6 +289,10 @@ int32_t ptx_film_resolve_device(int32_t device, int32_t width, int32_t height,
 int32_t ptx_film_resolve_banded_device(int32_t device, int32_t width, int32_t height, int32_t samples_per_pixel,
                                        const double* d_gathered, int32_t n_ranks, int32_t band_rows, int32_t pad_rows,
                                        double* d_rgb_out, void* stream);
+/* The same pass QUEUED on `stream` without waiting for it (the twin of PTX_RENDER_ASYNC: a rank that pipelines frames). */
+int32_t ptx_film_resolve_banded_queue(int32_t device, int32_t width, int32_t height, int32_t samples_per_pixel,
+                                      const double* d_gathered, int32_t n_ranks, int32_t band_rows, int32_t pad_rows,
+                                      double* d_rgb_out, void* stream);
 
 /* Per-sample radiance for explicit (x, y, pass) triples -- the value Integrator's
  * trace_path returns (integrator.ml:106).  Host in / host out, n*3 doubles.

@@ -33,7 +33,7 @@ EXPORTS = (
     "ptx_scene_stats", "ptx_render", "ptx_local_rows", "ptx_global_row", "ptx_render_raw_device",
     "ptx_film_resolve_device", "ptx_trace_samples", "ptx_intersect_rays", "ptx_scene_tree", "ptx_lds_sample",
     "ptx_math_eval", "ptx_ppm_render", "ptx_debug_first_scatter", "ptx_render_multi", "ptx_scene_replicate",
-    "ptx_film_resolve_banded_device", "ptx_release_workspaces",
+    "ptx_film_resolve_banded_device", "ptx_film_resolve_banded_queue", "ptx_release_workspaces",
 )
 
 PROGRESS_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_int64)
@@ -71,6 +71,7 @@ def lib():
     L.ptx_film_resolve_device.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
     L.ptx_film_resolve_banded_device.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_int32,
                                                  C.c_int32, C.c_void_p, C.c_void_p]
+    L.ptx_film_resolve_banded_queue.argtypes = L.ptx_film_resolve_banded_device.argtypes
     L.ptx_render_multi.argtypes = [C.POINTER(C.c_void_p), C.c_int32, C.POINTER(abi.RenderParams), dp, C.POINTER(abi.Stats),
                                    C.c_void_p, C.c_void_p]
     L.ptx_scene_replicate.restype = C.c_void_p
@@ -106,9 +107,10 @@ def _ip(a):
 
 
 def render_params(width, height, samples_per_pixel=1, max_bounces=8, band_rows=32, band_first=0, band_step=0,
-                  count_work=False, time_kernels=False, passes_per_batch=0, n_gpus=0):
+                  count_work=False, time_kernels=False, passes_per_batch=0, n_gpus=0, asynchronous=False):
     p = abi.RenderParams()
     p.n_gpus = n_gpus
+    p.flags = abi.PTX_RENDER_ASYNC if asynchronous else 0  # ptx_render_raw_device: queue the frame, do not wait for it
     p.width, p.height, p.samples_per_pixel, p.max_bounces = width, height, samples_per_pixel, max_bounces
     p.band_rows, p.band_first, p.band_step = band_rows, band_first, band_step
     p.count_work, p.time_kernels, p.passes_per_batch = int(count_work), int(time_kernels), passes_per_batch
@@ -242,10 +244,11 @@ def render_multi(scenes, width, height, samples_per_pixel, max_bounces, progress
 
 
 def film_resolve_banded_device(device, width, height, samples_per_pixel, d_gathered_ptr, n_ranks, band_rows, pad_rows,
-                               d_rgb_ptr, stream=None):
-    _check(lib().ptx_film_resolve_banded_device(device, width, height, samples_per_pixel, C.c_void_p(d_gathered_ptr),
-                                                n_ranks, band_rows, pad_rows, C.c_void_p(d_rgb_ptr),
-                                                C.c_void_p(stream) if stream else None))
+                               d_rgb_ptr, stream=None, wait=True):
+    """wait=False: ptx_film_resolve_banded_queue -- the pass is queued on `stream`, the call does not wait for it."""
+    fn = lib().ptx_film_resolve_banded_device if wait else lib().ptx_film_resolve_banded_queue
+    _check(fn(device, width, height, samples_per_pixel, C.c_void_p(d_gathered_ptr), n_ranks, band_rows, pad_rows,
+              C.c_void_p(d_rgb_ptr), C.c_void_p(stream) if stream else None))
 
 
 def film_resolve_device(device, width, height, samples_per_pixel, d_raw_ptr, d_rgb_ptr, stream=None):

@@ -13,6 +13,7 @@ PTX_BG_BLACK, PTX_BG_SKY = 0, 1
 PTX_LEAF_SIMD, PTX_LEAF_ARRAY = 0, 1
 PTX_KERNEL_NAMES = ("generate", "trace", "shade", "accum", "film", "bounce")
 PTX_N_KERNELS = 6
+PTX_RENDER_ASYNC = 1
 
 c_double_p = C.POINTER(C.c_double)
 c_int32_p = C.POINTER(C.c_int32)
@@ -55,7 +56,7 @@ class RenderParams(C.Structure):
         ("width", C.c_int32), ("height", C.c_int32), ("samples_per_pixel", C.c_int32), ("max_bounces", C.c_int32),
         ("band_rows", C.c_int32), ("band_first", C.c_int32), ("band_step", C.c_int32),
         ("count_work", C.c_int32), ("time_kernels", C.c_int32), ("passes_per_batch", C.c_int32),
-        ("n_gpus", C.c_int32), ("reserved", C.c_int32),
+        ("n_gpus", C.c_int32), ("flags", C.c_int32),
     ]
 
 

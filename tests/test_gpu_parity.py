@@ -446,6 +446,34 @@ def test_bounce_kernel_against_the_oracle(P, oracle, kind, fused, threads, wgs, 
     g.close()
 
 
+def test_queued_frames_equal_waited_frames(P, oracle):
+    """PTX_RENDER_ASYNC + ptx_film_resolve_banded_queue (what a rank that pipelines frames calls: bench.py's timed steps): three
+    frames queued back to back on one stream into the same buffers, nothing waited for in between, give the bits of a frame
+    rendered and resolved with the waiting calls -- the workspace, the raw sums and the framebuffer are reused in stream order."""
+    torch = pytest.importorskip("torch")
+    w, h, spp, depth = 320, 200, 6, 8
+    d = oracle.desc_shirley(w, h)
+    g = P.Scene(d.ptr, 0, keepalive=d)
+    stream = torch.cuda.current_stream().cuda_stream
+    raw_w = torch.zeros((h, w, 3), dtype=torch.float64, device="cuda:0")
+    rgb_w = torch.zeros_like(raw_w)
+    st = g.render_raw_device(P.render_params(w, h, spp, depth, band_rows=8), raw_w.data_ptr(), stream)
+    assert st["samples"] == w * h * spp
+    P.film_resolve_banded_device(0, w, h, spp, raw_w.data_ptr(), 1, 8, h, rgb_w.data_ptr(), stream)
+    raw_q = torch.full((h, w, 3), 7.0, dtype=torch.float64, device="cuda:0")
+    rgb_q = torch.zeros_like(raw_q)
+    pq = P.render_params(w, h, spp, depth, band_rows=8, asynchronous=True)
+    for _ in range(3):
+        g.render_raw_device(pq, raw_q.data_ptr(), stream)
+        P.film_resolve_banded_device(0, w, h, spp, raw_q.data_ptr(), 1, 8, h, rgb_q.data_ptr(), stream, wait=False)
+    torch.cuda.synchronize()
+    assert np.array_equal(bits(raw_q.cpu().numpy()), bits(raw_w.cpu().numpy()))
+    assert np.array_equal(bits(rgb_q.cpu().numpy()), bits(rgb_w.cpu().numpy()))
+    c = oracle.Scene(d.ptr, d).render(w, h, spp, depth, threads=8, want_raw=True)
+    assert np.array_equal(bits(raw_q.cpu().numpy()), bits(c["raw"]))
+    g.close()
+
+
 @pytest.mark.parametrize("kind", ["shirley", "cornell", "ganesha"])
 def test_the_three_shade_stage_implementations_agree(P, oracle, kind, monkeypatch):
     """The default k_shade_pool (per-wave category pools, blocked output queue with holes), k_shade (category-sorted
