@@ -315,7 +315,8 @@ __device__ __forceinline__ bool pt_slab_hit_exact(const double* nb, V3 o, V3 inv
  * max|1/d| > 2^-60 (else: always binary64):
  *   t~ = fma32(bound32, inv32, -(o * inv)32) differs from the reference's fl64((bound - o) * inv) by at most
  *        3.2 * 2^-24 * (|bound| + |o|) * |inv|  <=  M := 3.2 * 2^-24 * (mag + max|o|) * max|inv|
- *   (three binary32 roundings of the inputs, one of the fma, the reference's own two binary64 roundings);
+ *   (three binary32 roundings of the inputs, one of the fma, the reference's own two binary64 roundings; with PT_F32_INV,
+ *   where inv32 and (o inv)32 are computed in binary32 from the start: 6 instead of 3.2, see PtTraverser::begin);
  *   max / min are 1-Lipschitz, so lo~ = max(0, a~) and hi~ = min(b~, t32) are within M (+ 2^-24 t for the rounded
  *   closest-hit distance) of the reference's lo, hi, and u = hi~ - lo~ (one more rounding) within 8.4 * 2^-24 * (..)
  *   + 2^-24 t of hi - lo.  With m2 = 2^-19 * (mag + max|o|) * max|inv| + 2^-21 * t32  (twice that bound):
@@ -425,6 +426,9 @@ __device__ __forceinline__ uint32_t pt_stack_pop(const PtThreadTag*, int) { retu
 #ifndef PT_LEAF_PREFETCH
 #define PT_LEAF_PREFETCH 1 /* triangle-only scenes walked from HBM / L2: request triangle k + 1 before testing triangle k */
 #endif
+#ifndef PT_F32_INV
+#define PT_F32_INV 1 /* the filter's reciprocals by v_rcp_f32 instead of Ray.create's three binary64 divisions (PtTraverser::begin) */
+#endif
 #ifndef PT_LEAN_FALLBACK
 #define PT_LEAN_FALLBACK 1
 #endif
@@ -482,10 +486,15 @@ struct PtTraverser {
                                         unsigned long long& c_floor) {
     o = o_;
     d = d_;
-    inv = v3(1.0 / d.x, 1.0 / d.y, 1.0 / d.z); /* Ray.create, ray.ml:7-10 */
     /* dirs, shape_tree.ml:201 */
     dirs = (d.x >= 0.0 ? 1u : 0u) | (d.y >= 0.0 ? 2u : 0u) | (d.z >= 0.0 ? 4u : 0u);
-    exact_slab = !(pt_isfinite(inv.x) && pt_isfinite(inv.y) && pt_isfinite(inv.z));
+    if (!FILT || !PT_F32_INV) {
+      inv = v3(1.0 / d.x, 1.0 / d.y, 1.0 / d.z); /* Ray.create, ray.ml:7-10 */
+      exact_slab = !(pt_isfinite(inv.x) && pt_isfinite(inv.y) && pt_isfinite(inv.z));
+    } else {
+      inv = v3(0.0, 0.0, 0.0); /* the filter takes its reciprocals in binary32 (below); the binary64 fallback divides for itself */
+      exact_slab = false;
+    }
     if (FILT) {
 #if PT_SWZ_SIGNSEL
       skip_off = 2u * dirs;
@@ -497,21 +506,43 @@ struct PtTraverser {
 #else
       skip_off = PT_SWZ_OFF_SKIP + 2u * dirs;
 #endif
+      const double omax = __builtin_fmax(pt_fabs(o.x), __builtin_fmax(pt_fabs(o.y), pt_fabs(o.z)));
+#if PT_F32_INV
+      /* The filter's constants straight in binary32: inv32 = v_rcp_f32(fl32(d)) (1 ulp) is within 3 * 2^-24 of 1 / d and
+       * (o inv)32 = fl32(fl32(o) inv32) within 5 * 2^-24 of o / d, instead of one rounding each from Ray.create's binary64
+       * quotients -- three binary64 divisions per ray (~40 vector instructions of a walk's ~1000) that only the filter used.
+       * The bound above becomes 6 (t~) and 13 (u) units of 2^-24 (..) against m2 = 32 of them: still more than twice.  A zero,
+       * subnormal or NaN component gives inf / NaN here and fails the guard below (binary64 throughout, as before); a
+       * component beyond binary32 gives inv32 = 0 for a true |1 / d| < 2^-127, the flush case the guard's comment covers. */
+      fix = __builtin_amdgcn_rcpf((float)d.x);
+      fiy = __builtin_amdgcn_rcpf((float)d.y);
+      fiz = __builtin_amdgcn_rcpf((float)d.z);
+      const float fimax = __builtin_fmaxf(__builtin_fabsf(fix), __builtin_fmaxf(__builtin_fabsf(fiy), __builtin_fabsf(fiz)));
+      const float fisum = __builtin_fabsf(fix) + __builtin_fabsf(fiy) + __builtin_fabsf(fiz); /* (fmax drops a NaN, a sum keeps it) */
+#else
       const double ax = pt_fabs(inv.x), ay = pt_fabs(inv.y), az = pt_fabs(inv.z);
       const double imax = __builtin_fmax(ax, __builtin_fmax(ay, az));
-      const double omax = __builtin_fmax(pt_fabs(o.x), __builtin_fmax(pt_fabs(o.y), pt_fabs(o.z)));
+#endif
       /* every binary32 intermediate stays far inside the format: (mag + |o|) |inv| < 2^100 for every node, because every
        * node lies inside the root box (root_mag = its largest |coordinate|, +inf when that exceeds binary32: such a scene
        * is walked in binary64 throughout), so no product, sum or margin of the filter can overflow, whatever the scene's
        * scale.  And max|1/d| is kept far above the binary32 subnormals (>= 2^-60): components of inv32 / (o inv)32 that
        * are subnormal -- or flushed to zero, whatever the f32 denormal mode of the code object -- are then wrong by
        * < 2^-126 (mag + |o|) absolute, which m2 >= 2^-19 (mag + |o|) 2^-60 + 1e-30 covers with room to spare. */
-      const float fimax = (float)imax, fomax = (float)omax; /* (a magnitude beyond binary32 becomes +inf and fails the guard) */
+      const float fomax = (float)omax; /* (a magnitude beyond binary32 becomes +inf and fails the guard) */
+#if PT_F32_INV
+      if (!((sc.root_mag + fomax) * fisum < 0x1p100f) || !(fimax > 0x1p-60f)) exact_slab = true;
+      fnx = ORIGIN_ZERO ? 0.0f : -((float)o.x * fix);
+      fny = ORIGIN_ZERO ? 0.0f : -((float)o.y * fiy);
+      fnz = ORIGIN_ZERO ? 0.0f : -((float)o.z * fiz);
+#else
+      const float fimax = (float)imax;
       if (!((sc.root_mag + fomax) * fimax < 0x1p100f) || !(fimax > 0x1p-60f)) exact_slab = true;
       fix = (float)inv.x; fiy = (float)inv.y; fiz = (float)inv.z;
       fnx = ORIGIN_ZERO ? 0.0f : -(float)(o.x * inv.x);
       fny = ORIGIN_ZERO ? 0.0f : -(float)(o.y * inv.y);
       fnz = ORIGIN_ZERO ? 0.0f : -(float)(o.z * inv.z);
+#endif
       k2 = fimax * 0x1.000002p-19f;
       c2base = __builtin_fmaf(fomax * 1.000001f, k2, 1e-30f);
       /* exact_slab folded into the margin: with m2 = NaN neither `u >= m2` nor `u < -m2` holds, so every test of such a ray
@@ -562,6 +593,31 @@ struct PtTraverser {
    * stack (far children only) lives in LDS, one column per lane (conflict-free ds_write / ds_read).  A far child's
    * bbox is tested when it is POPPED, against the closest hit so far -- exactly the t_max the reference's recursion
    * passes (shape_tree.ml:210-216). */
+  /* the reference's own arithmetic on the binary64 node `np` (the filter could not decide): 1 / d again -- the same three
+   * divisions as Ray.create, opaque to the optimiser, or it hoists them out of the walk and keeps six more registers live
+   * across the hot loop */
+  __device__ __forceinline__ bool slab64(const PtNode* np) const {
+    double qx = d.x, qy = d.y, qz = d.z;
+    asm volatile("" : "+v"(qx), "+v"(qy), "+v"(qz));
+    const V3 inv64 = v3(1.0 / qx, 1.0 / qy, 1.0 / qz);
+    return (!(pt_isfinite(inv64.x) && pt_isfinite(inv64.y) && pt_isfinite(inv64.z))) ? pt_slab_hit_exact(np->mn, o, inv64, 0.0, r.t)
+                                                                                     : pt_slab_hit_fast<ORIGIN_ZERO>(np->mn, o, inv64, 0.0, r.t);
+  }
+  /* A box that is FLAT along exactly one axis k (mn[k] == mx[k]: an axis-aligned wall's triangles, cornell's whole room):
+   * near_k == far_k == T bit for bit, in the filter and in the reference alike, so lo >= T >= hi always and
+   *   hit  <=>  max(0, near of the other two) <= T <= min(t_max, far of the other two)
+   * -- the generic u = hi - lo is exactly 0 on every hit and the filter can never say so (cornell: 4.7 % of all tests, a
+   * binary64 fallback in 31 % of the wave steps).  The two one-sided gaps carry the same error bound as u, so the same
+   * margin decides them: 1 = hit, 0 = miss, -1 = still undecided (NaNs and near-ties fall through to binary64). */
+  __device__ __forceinline__ int flat_decide(uint32_t flat, float tnx, float tfx, float tny, float tfy, float tnz, float tfz, float m2) const {
+    if (flat != 1u && flat != 2u && flat != 4u) return -1;
+    const float T = flat == 1u ? tnx : (flat == 2u ? tny : tnz);
+    const float n1 = flat == 1u ? tny : tnx, n2 = flat == 4u ? tny : tnz;
+    const float f1 = flat == 1u ? tfy : tfx, f2 = flat == 4u ? tfy : tfz;
+    const float lo = __builtin_fmaxf(__builtin_fmaxf(n1, n2), 0.0f), hi = __builtin_fminf(__builtin_fminf(f1, f2), t32);
+    const float uf = __builtin_fminf(T - lo, hi - T);
+    return uf >= m2 ? 1 : (uf <= -m2 ? 0 : -1);
+  }
   /* Bbox.is_hit of `nd` against the closest hit so far + the node's links (a, b, real slot count) */
   __device__ __forceinline__ bool test_box(const PtSceneView& sv, uint32_t nd, uint32_t& na, uint32_t& nb, uint32_t& n_real, bool active = true) const {
     const double t_min = 0.0;
@@ -586,37 +642,16 @@ struct PtTraverser {
         const float u = __builtin_fminf(b, t32) - __builtin_fmaxf(a, 0.0f);
         const float m2 = __builtin_fmaf(__uint_as_float(lk.y), k2, c2);
         hit = u >= m2;
-#if PT_LEAN_FALLBACK
-        if (!COUNT) {
-          /* one divergent branch, no wave-uniform pre-check: two scalar instructions per visit instead of five (at 4 waves per
-           * SIMD the scalar instructions of a visit -- 27 against 22 vector ones -- are no longer free) */
-          if (active && !(__builtin_fabsf(u) >= m2)) {
-            const PtNode* np = sv.nodes + (nd - sv.swz_root) / PT_SWZ_NODE_BYTES;
-            double qx = d.x, qy = d.y, qz = d.z;
-            asm volatile("" : "+v"(qx), "+v"(qy), "+v"(qz));
-            const V3 inv64 = v3(1.0 / qx, 1.0 / qy, 1.0 / qz);
-            hit = (!(pt_isfinite(inv64.x) && pt_isfinite(inv64.y) && pt_isfinite(inv64.z)))
-                      ? pt_slab_hit_exact(np->mn, o, inv64, t_min, r.t)
-                      : pt_slab_hit_fast<ORIGIN_ZERO>(np->mn, o, inv64, t_min, r.t);
+        /* one divergent branch, no wave-uniform pre-check: two scalar instructions per visit instead of five (at 4 waves per
+         * SIMD the scalar instructions of a visit -- 27 against 22 vector ones -- are no longer free) */
+        if (active && !(__builtin_fabsf(u) >= m2)) {
+          const int dec = flat_decide((lk.y >> 2) & 7u, tnx, tfx, tny, tfy, tnz, tfz, m2);
+          if (dec >= 0) hit = dec != 0;
+          else {
+            if (COUNT) n_undecided++;
+            hit = slab64(sv.nodes + (nd - sv.swz_root) / PT_SWZ_NODE_BYTES);
           }
-          return hit;
-        }
-#endif
-        if (__builtin_amdgcn_fcmpf(__builtin_fabsf(u), active ? m2 : 0.0f, 12) != 0) { /* as below */
-          const bool undecided = active && !(__builtin_fabsf(u) >= m2);
-          if (COUNT) {
-            if (undecided) n_undecided++;
-            if (pt_lane() == __ffsll((long long)__ballot(1)) - 1) n_wave_fallbacks++;
-          }
-          if (undecided) {
-            const PtNode* np = sv.nodes + (nd - sv.swz_root) / PT_SWZ_NODE_BYTES;
-            double qx = d.x, qy = d.y, qz = d.z;
-            asm volatile("" : "+v"(qx), "+v"(qy), "+v"(qz));
-            const V3 inv64 = v3(1.0 / qx, 1.0 / qy, 1.0 / qz);
-            hit = (!(pt_isfinite(inv64.x) && pt_isfinite(inv64.y) && pt_isfinite(inv64.z)))
-                      ? pt_slab_hit_exact(np->mn, o, inv64, t_min, r.t)
-                      : pt_slab_hit_fast<ORIGIN_ZERO>(np->mn, o, inv64, t_min, r.t);
-          }
+          if (COUNT && __ballot(dec < 0) != 0 && pt_lane() == __ffsll((long long)__ballot(1)) - 1) n_wave_fallbacks++;
         }
         return hit;
       }
@@ -1358,7 +1393,9 @@ __device__ __forceinline__ PtSceneView pt_scene_view(const PtSceneDev& sc, unsig
       lk[0] = leaf ? ((src->a & 0xffffu) | ((src->pad[0] & 0xffffu) << 16))
                    : ((nbase + src->a * PT_SWZ_NODE_BYTES) | ((nbase + (src->b & 0x3fffffffu) * PT_SWZ_NODE_BYTES) << 16));
       /* rounded up, then the two lowest mantissa bits carry the axis (a relative change below 2^-21, inside the slack) */
-      lk[1] = ((__float_as_uint(mag * 1.000001f) + 4u) & ~3u) | axis;
+      /* ... and the next three which axes the box is flat along (PtTraverser::flat_decide): below 2^-18 in all, rounded UP */
+      const uint32_t flat = (src->mn[0] == src->mx[0] ? 1u : 0u) | (src->mn[1] == src->mx[1] ? 2u : 0u) | (src->mn[2] == src->mx[2] ? 4u : 0u);
+      lk[1] = ((__float_as_uint(mag * 1.000001f) + 32u) & ~31u) | axis | (flat << 2);
       uint16_t* sk = (uint16_t*)((unsigned char*)w + PT_SWZ_OFF_SKIP);
       for (int o = 0; o < 8; ++o) {
         const uint32_t nx = sc.node_skip[(size_t)k * 8 + o];

@@ -151,6 +151,52 @@ def test_bounds_beyond_binary32_range(P, oracle, leaf_kind, cutoff, scale):
         assert (prims >= 0).sum() > 100
 
 
+def wall_soup(rng, n, scale, centre):
+    """n axis-aligned rectangles (two triangles each): every triangle's box -- and every leaf that holds only coplanar ones -- is
+    FLAT along one axis, the case PtTraverser::flat_decide settles in binary32."""
+    tris = []
+    for _ in range(n):
+        k = int(rng.integers(0, 3))
+        i, j = (k + 1) % 3, (k + 2) % 3
+        p = centre + rng.uniform(-1.0, 1.0, 3) * scale
+        ei, ej = scale * 10.0 ** rng.uniform(-3.0, 0.0, 2)
+        q = [p.copy() for _ in range(4)]
+        q[1][i] += ei
+        q[2][i] += ei
+        q[2][j] += ej
+        q[3][j] += ej
+        m = int(rng.integers(0, 3))
+        tris += [(q[0], q[1], q[2], m), (q[0], q[2], q[3], m)]
+    return tris
+
+
+@pytest.mark.parametrize("seed,scale,cutoff", [(50, 1.0, 4), (51, 2.0 ** -11, 2), (52, 2.0 ** 18, 1), (53, 1.0, 1)])
+def test_flat_boxes_axis_aligned_walls(P, oracle, seed, scale, cutoff):
+    """Boxes of zero thickness: on every hit the slab test's hi - lo is exactly 0, so the generic filter can never decide it; the
+    flat-box rule decides most of them in binary32 and must agree with the reference's boolean on all of them -- rays through
+    the rectangles, along their planes, and through the edges of their (flat) boxes within +-4 binary32 ulps."""
+    from path_tracer_ocaml_amd import abi
+    rng = np.random.default_rng(1000 + seed)
+    centre = rng.uniform(-1.0, 1.0, 3) * scale * 3.0
+    d, keep = make_desc(abi, tris=wall_soup(rng, 200, scale, centre), leaf_kind=1, cutoff=cutoff)
+    o_scene, g_scene = both(P, oracle, d, keep)
+    assert g_scene.stats()["traversal_in_lds"]
+    boxes = leaf_boxes(g_scene)
+    flat = boxes[(boxes[:, :3] == boxes[:, 3:]).any(axis=1)]
+    assert len(flat) > 20, "the scene was meant to have flat boxes"
+    o, dr = ray_mix(rng, 30000, scale, centre, boxes)
+    # a share of the rays exactly inside a wall's plane
+    k = 3000
+    bx = flat[rng.integers(0, len(flat), k)]
+    ax = np.argmax(bx[:, :3] == bx[:, 3:], axis=1)
+    o[:k, :] = centre + rng.uniform(-1.0, 1.0, (k, 3)) * scale
+    o[np.arange(k), ax] = bx[np.arange(k), ax]
+    dr[:k] = rng.normal(size=(k, 3))
+    dr[np.arange(k), ax] = 0.0
+    prims = check_rays(o_scene, g_scene, o, dr)
+    assert (prims >= 0).sum() > 300 and (prims < 0).sum() > 300
+
+
 def test_every_test_undecided_when_margin_is_everything(P, oracle):
     """A scene of identical concentric boxes seen edge-on: a large share of the tests is undecided; counters still equal."""
     from path_tracer_ocaml_amd import abi
