@@ -426,6 +426,10 @@ __device__ __forceinline__ uint32_t pt_stack_pop(const PtThreadTag*, int) { retu
 #ifndef PT_LEAF_PREFETCH
 #define PT_LEAF_PREFETCH 1 /* triangle-only scenes walked from HBM / L2: request triangle k + 1 before testing triangle k */
 #endif
+#ifndef PT_MARGIN_K2
+#define PT_MARGIN_K2 0x1.000002p-19f /* the filter's margin m2 = PT_MARGIN_K2 (mag + max|o|) max|1/d| + PT_MARGIN_T t (header comment) */
+#define PT_MARGIN_T 0x1p-21f
+#endif
 #ifndef PT_F32_INV
 #define PT_F32_INV 1 /* the filter's reciprocals by v_rcp_f32 instead of Ray.create's three binary64 divisions (PtTraverser::begin) */
 #endif
@@ -543,7 +547,7 @@ struct PtTraverser {
       fny = ORIGIN_ZERO ? 0.0f : -(float)(o.y * inv.y);
       fnz = ORIGIN_ZERO ? 0.0f : -(float)(o.z * inv.z);
 #endif
-      k2 = fimax * 0x1.000002p-19f;
+      k2 = fimax * PT_MARGIN_K2;
       c2base = __builtin_fmaf(fomax * 1.000001f, k2, 1e-30f);
       /* exact_slab folded into the margin: with m2 = NaN neither `u >= m2` nor `u < -m2` holds, so every test of such a ray
        * is undecided and takes the binary64 code -- no per-visit instruction for the flag itself */
@@ -586,7 +590,7 @@ struct PtTraverser {
   /* the closest hit so far as the filter sees it; called whenever r.t may have changed */
   __device__ __forceinline__ void update_t32() {
     t32 = (float)r.t; /* PT_MAX_FINITE -> +inf */
-    c2 = c2base + (t32 < 0x1p120f ? t32 * 0x1p-21f : 0.0f);
+    c2 = c2base + (t32 < 0x1p120f ? t32 * PT_MARGIN_T : 0.0f);
   }
 
   /* Visit `node`: bbox test against the closest hit so far, then descend / hold the leaf / pop.  The traversal
