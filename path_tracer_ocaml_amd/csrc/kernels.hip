@@ -433,9 +433,6 @@ __device__ __forceinline__ uint32_t pt_stack_pop(const PtThreadTag*, int) { retu
 #ifndef PT_F32_INV
 #define PT_F32_INV 1 /* the filter's reciprocals by v_rcp_f32 instead of Ray.create's three binary64 divisions (PtTraverser::begin) */
 #endif
-#ifndef PT_LEAN_FALLBACK
-#define PT_LEAN_FALLBACK 1
-#endif
 #ifndef PT_WALK_LOOP
 #define PT_WALK_LOOP 0 /* 0: wave-level loop with a `want` ballot per turn; 1: the node walk as one divergent loop (fewer scalar
                           instructions per turn, but the kernel is bound by VECTOR issue: measured 3 % slower) */
@@ -607,20 +604,18 @@ struct PtTraverser {
     return (!(pt_isfinite(inv64.x) && pt_isfinite(inv64.y) && pt_isfinite(inv64.z))) ? pt_slab_hit_exact(np->mn, o, inv64, 0.0, r.t)
                                                                                      : pt_slab_hit_fast<ORIGIN_ZERO>(np->mn, o, inv64, 0.0, r.t);
   }
-  /* A box that is FLAT along exactly one axis k (mn[k] == mx[k]: an axis-aligned wall's triangles, cornell's whole room):
-   * near_k == far_k == T bit for bit, in the filter and in the reference alike, so lo >= T >= hi always and
-   *   hit  <=>  max(0, near of the other two) <= T <= min(t_max, far of the other two)
-   * -- the generic u = hi - lo is exactly 0 on every hit and the filter can never say so (cornell: 4.7 % of all tests, a
-   * binary64 fallback in 31 % of the wave steps).  The two one-sided gaps carry the same error bound as u, so the same
-   * margin decides them: 1 = hit, 0 = miss, -1 = still undecided (NaNs and near-ties fall through to binary64). */
-  __device__ __forceinline__ int flat_decide(uint32_t flat, float tnx, float tfx, float tny, float tfy, float tnz, float tfz, float m2) const {
-    if (flat != 1u && flat != 2u && flat != 4u) return -1;
-    const float T = flat == 1u ? tnx : (flat == 2u ? tny : tnz);
-    const float n1 = flat == 1u ? tny : tnx, n2 = flat == 4u ? tny : tnz;
-    const float f1 = flat == 1u ? tfy : tfx, f2 = flat == 4u ? tfy : tfz;
-    const float lo = __builtin_fmaxf(__builtin_fmaxf(n1, n2), 0.0f), hi = __builtin_fminf(__builtin_fminf(f1, f2), t32);
-    const float uf = __builtin_fminf(T - lo, hi - T);
-    return uf >= m2 ? 1 : (uf <= -m2 ? 0 : -1);
+  /* What the generic u = hi - lo cannot decide although it is certain: ONE axis k whose slab interval [near_k, far_k] lies
+   * inside the other two axes' intervals and inside [0, t_max] by the margin.  Then the reference's lo IS near_k and its hi IS
+   * far_k, and near_k <= far_k holds by construction (the min and the max of the same two products): a hit, however small
+   * far_k - near_k is -- and it is exactly 0 for a box that is flat along k (an axis-aligned wall's triangles: cornell's whole
+   * room -- 4.7 % of its box tests were undecided and 31 % of its wave steps ran the binary64 fallback), tiny for thin boxes.
+   * Each one-sided gap carries the same error bound as u, so the same margin decides it.  false = still undecided (near-ties
+   * between DIFFERENT axes, NaNs): binary64. */
+  __device__ __forceinline__ bool nested_hit(float tnx, float tfx, float tny, float tfy, float tnz, float tfz, float m2) const {
+    const float lx = __builtin_fmaxf(__builtin_fmaxf(tny, tnz), 0.0f), hx = __builtin_fminf(__builtin_fminf(tfy, tfz), t32);
+    const float ly = __builtin_fmaxf(__builtin_fmaxf(tnx, tnz), 0.0f), hy = __builtin_fminf(__builtin_fminf(tfx, tfz), t32);
+    const float lz = __builtin_fmaxf(__builtin_fmaxf(tnx, tny), 0.0f), hz = __builtin_fminf(__builtin_fminf(tfx, tfy), t32);
+    return (tnx - lx >= m2 && hx - tfx >= m2) || (tny - ly >= m2 && hy - tfy >= m2) || (tnz - lz >= m2 && hz - tfz >= m2);
   }
   /* Bbox.is_hit of `nd` against the closest hit so far + the node's links (a, b, real slot count) */
   __device__ __forceinline__ bool test_box(const PtSceneView& sv, uint32_t nd, uint32_t& na, uint32_t& nb, uint32_t& n_real, bool active = true) const {
@@ -649,13 +644,13 @@ struct PtTraverser {
         /* one divergent branch, no wave-uniform pre-check: two scalar instructions per visit instead of five (at 4 waves per
          * SIMD the scalar instructions of a visit -- 27 against 22 vector ones -- are no longer free) */
         if (active && !(__builtin_fabsf(u) >= m2)) {
-          const int dec = flat_decide((lk.y >> 2) & 7u, tnx, tfx, tny, tfy, tnz, tfz, m2);
-          if (dec >= 0) hit = dec != 0;
+          const bool nested = nested_hit(tnx, tfx, tny, tfy, tnz, tfz, m2);
+          if (nested) hit = true;
           else {
             if (COUNT) n_undecided++;
             hit = slab64(sv.nodes + (nd - sv.swz_root) / PT_SWZ_NODE_BYTES);
           }
-          if (COUNT && __ballot(dec < 0) != 0 && pt_lane() == __ffsll((long long)__ballot(1)) - 1) n_wave_fallbacks++;
+          if (COUNT && __ballot(!nested) != 0 && pt_lane() == __ffsll((long long)__ballot(1)) - 1) n_wave_fallbacks++;
         }
         return hit;
       }
@@ -694,45 +689,19 @@ struct PtTraverser {
       const float u = __builtin_fminf(b, t32) - __builtin_fmaxf(a, 0.0f);
       const float m2 = __builtin_fmaf(mag, k2, c2);
       hit = u >= m2;
-      /* (a ray the filter does not apply to carries m2 = NaN: neither comparison holds, every test of it is undecided) */
-      /* one comparison, so that the ballot below is that comparison's own mask (a boolean assembled from two costs two more
-       * vector instructions per visit): |u| < m2 or unordered.  u == -m2 exactly now counts as a decided miss: it is one,
-       * m2 is twice the error bound */
-      /* (the wave mask straight from the comparison -- predicate 12 = unordered or less than; a ballot of the boolean that the
-       * branch below also uses makes the compiler materialise it per lane first) */
-#if PT_LEAN_FALLBACK
-      if (!COUNT) { /* as in the layout-3 branch above: one divergent branch */
-        if (active && !(__builtin_fabsf(u) >= m2)) {
-          const PtNode* np = sv.nodes + (SWZ ? nd / PT_SWZ_NODE_BYTES
-                                             : ((nd & PT_TOP_FLAG) ? *(const uint32_t*)(sv.top + (nd & (PT_TOP_FLAG - 1u)) + 48) : nd));
-          double qx = d.x, qy = d.y, qz = d.z;
-          asm volatile("" : "+v"(qx), "+v"(qy), "+v"(qz));
-          const V3 inv64 = v3(1.0 / qx, 1.0 / qy, 1.0 / qz);
-          hit = (!(pt_isfinite(inv64.x) && pt_isfinite(inv64.y) && pt_isfinite(inv64.z)))
-                    ? pt_slab_hit_exact(np->mn, o, inv64, t_min, r.t)
-                    : pt_slab_hit_fast<ORIGIN_ZERO>(np->mn, o, inv64, t_min, r.t);
-        }
-        return hit;
-      }
-#endif
-      if (__builtin_amdgcn_fcmpf(__builtin_fabsf(u), active ? m2 : 0.0f, 12) != 0) {
-        const bool undecided = active && !(__builtin_fabsf(u) >= m2);
+      /* (a ray the filter does not apply to carries m2 = NaN: neither comparison holds, every test of it is undecided.)
+       * One comparison |u| >= m2 (u == -m2 exactly counts as a decided miss: it is one, m2 is twice the error bound) and one
+       * divergent branch, no wave-uniform pre-check -- see the layout-3 branch above */
+      if (active && !(__builtin_fabsf(u) >= m2)) {
+        /* (no nested_hit here: on a mesh walked from HBM / L2 it settles 7 % of the undecided tests and its twenty
+         * instructions in 22 % of the wave steps cost 3 % of the frame) */
         if (COUNT) {
-          if (undecided) n_undecided++;
+          n_undecided++;
           if (pt_lane() == __ffsll((long long)__ballot(1)) - 1) n_wave_fallbacks++;
         }
-        if (undecided) { /* the reference's arithmetic, on the binary64 node (global memory: L2-resident, rarely read) */
-          const PtNode* np = sv.nodes + (SWZ ? nd / PT_SWZ_NODE_BYTES
-                                             : ((nd & PT_TOP_FLAG) ? *(const uint32_t*)(sv.top + (nd & (PT_TOP_FLAG - 1u)) + 48) : nd));
-          /* 1 / d again (the same three divisions as Ray.create): opaque to the optimiser, or it hoists them out of the
-           * walk and keeps six more registers live across the hot loop for a path taken in 1.6 % of the wave-steps */
-          double qx = d.x, qy = d.y, qz = d.z;
-          asm volatile("" : "+v"(qx), "+v"(qy), "+v"(qz));
-          const V3 inv64 = v3(1.0 / qx, 1.0 / qy, 1.0 / qz);
-          hit = (!(pt_isfinite(inv64.x) && pt_isfinite(inv64.y) && pt_isfinite(inv64.z)))
-                    ? pt_slab_hit_exact(np->mn, o, inv64, t_min, r.t)
-                    : pt_slab_hit_fast<ORIGIN_ZERO>(np->mn, o, inv64, t_min, r.t);
-        }
+        /* the reference's arithmetic, on the binary64 node (global memory: L2-resident, rarely read) */
+        hit = slab64(sv.nodes + (SWZ ? nd / PT_SWZ_NODE_BYTES
+                                     : ((nd & PT_TOP_FLAG) ? *(const uint32_t*)(sv.top + (nd & (PT_TOP_FLAG - 1u)) + 48) : nd)));
       }
     } else {
       const PtNode* np = sv.nodes + nd;
@@ -1397,9 +1366,7 @@ __device__ __forceinline__ PtSceneView pt_scene_view(const PtSceneDev& sc, unsig
       lk[0] = leaf ? ((src->a & 0xffffu) | ((src->pad[0] & 0xffffu) << 16))
                    : ((nbase + src->a * PT_SWZ_NODE_BYTES) | ((nbase + (src->b & 0x3fffffffu) * PT_SWZ_NODE_BYTES) << 16));
       /* rounded up, then the two lowest mantissa bits carry the axis (a relative change below 2^-21, inside the slack) */
-      /* ... and the next three which axes the box is flat along (PtTraverser::flat_decide): below 2^-18 in all, rounded UP */
-      const uint32_t flat = (src->mn[0] == src->mx[0] ? 1u : 0u) | (src->mn[1] == src->mx[1] ? 2u : 0u) | (src->mn[2] == src->mx[2] ? 4u : 0u);
-      lk[1] = ((__float_as_uint(mag * 1.000001f) + 32u) & ~31u) | axis | (flat << 2);
+      lk[1] = ((__float_as_uint(mag * 1.000001f) + 4u) & ~3u) | axis;
       uint16_t* sk = (uint16_t*)((unsigned char*)w + PT_SWZ_OFF_SKIP);
       for (int o = 0; o < 8; ++o) {
         const uint32_t nx = sc.node_skip[(size_t)k * 8 + o];
