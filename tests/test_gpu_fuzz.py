@@ -153,7 +153,7 @@ def test_bounds_beyond_binary32_range(P, oracle, leaf_kind, cutoff, scale):
 
 def wall_soup(rng, n, scale, centre):
     """n axis-aligned rectangles (two triangles each): every triangle's box -- and every leaf that holds only coplanar ones -- is
-    FLAT along one axis, the case PtTraverser::flat_decide settles in binary32."""
+    FLAT along one axis, the case PtTraverser::nested_hit settles in binary32."""
     tris = []
     for _ in range(n):
         k = int(rng.integers(0, 3))
