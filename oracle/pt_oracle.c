@@ -59,6 +59,17 @@ ORC_API double orc_math(int fn, double a, double b) {
     case 6: return sqrt(a);
     case 7: return a / b;
     case 8: return fma(a, b, b);
+    /* the product's fused normalisation scalars (pt_rnorm3 / pt_rnorm_frame) and bare sqrt / reciprocal / division sequences
+     * against the literal expressions they stand for */
+    case 9: return 1.0 / m_hypot(a, m_hypot(b, a - b));                    /* V3.normalize, affine.ml:65-68 */
+    case 10: return 1.0 / m_hypot(m_hypot(1.0 + a, b), m_hypot(a - b, 0.0)); /* Quaternion.normalize, quaternion.ml:11-15 */
+    case 11: return sqrt(a);
+    case 12: return 1.0 / a;
+    case 13: return a / b;
+    case 14: return sqrt(a);
+    /* the fused forms themselves, host build (tests/test_math.py compares them with cases 9 / 10 without a GPU) */
+    case 19: return pt_rnorm3(a, b, a - b);
+    case 20: return pt_rnorm_frame(1.0 + a, b, a - b);
   }
   return NAN;
 }

@@ -272,7 +272,8 @@ def lds_sample(dimension, offsets, dims, device=0):
     return out
 
 
-MATH_FN = {"hypot": 0, "sin": 1, "cos": 2, "acos": 3, "atan2": 4, "pow5": 5, "sqrt": 6, "div": 7, "fma": 8}
+MATH_FN = {"hypot": 0, "sin": 1, "cos": 2, "acos": 3, "atan2": 4, "pow5": 5, "sqrt": 6, "div": 7, "fma": 8,
+           "rnorm3": 9, "rnorm_frame": 10, "sqrt_nonneg": 11, "rcp_mid": 12, "div_mid": 13, "sqrt_mid": 14}
 
 
 def math_eval(fn, a, b=None, device=0):

@@ -1907,7 +1907,7 @@ __host__ __device__ __forceinline__ Quat pt_shader_rotation(V3 normal) {
   } else {
     const double r = 1.0 + normal.z;
     const V3 v = v3(normal.y, -normal.x, 0.0);
-    const double s = 1.0 / pt_hypot(pt_hypot(r, v.x), pt_hypot(v.y, v.z));
+    const double s = pt_rnorm_frame(r, v.x, v.y); /* v.z = 0 */
     q.r = r * s;
     q.v = v3_scale(v, s);
   }
@@ -2082,7 +2082,7 @@ __device__ __forceinline__ PtScatter pt_material_scatter(const PtSceneDev& sc, c
     const double index = m.index, index_inv = 1.0 / m.index;
     const double wi_z = omega_i.z;
     const double c = wi_z < 0.0 ? 0.0 : (1.0 < wi_z ? 1.0 : wi_z); /* Float.clamp_exn */
-    const double sn = pt_sqrt(1.0 - c * c);
+    const double sn = pt_sqrt_nonneg(1.0 - c * c);
     const double refract_ratio = sf.hit_front ? index_inv : index;
     /* Both candidate directions are cheap: evaluate them unconditionally and select.  (A divergent
      * `a || f(x) > u` branch here was miscompiled by hipcc -O3 -- caught by the bit-exact sample test.) */
@@ -2090,7 +2090,7 @@ __device__ __forceinline__ PtScatter pt_material_scatter(const PtSceneDev& sc, c
     /* Shader_space.refract (shader_space.ml:41-49) */
     const double cc = pt_base_min(omega_i.z, 1.0);
     const V3 perp = v3_scale(v3_sub(v3(0.0, 0.0, cc), omega_i), refract_ratio);
-    const V3 para = v3(0.0, 0.0, -pt_sqrt(pt_fabs(1.0 - v3_quadrance(perp))));
+    const V3 para = v3(0.0, 0.0, -pt_sqrt_nonneg(pt_fabs(1.0 - v3_quadrance(perp))));
     const V3 refr = v3_add(perp, para);
     r.wo.x = reflect ? -omega_i.x : refr.x; /* Shader_space.reflect (shader_space.ml:34-39) */
     r.wo.y = reflect ? -omega_i.y : refr.y;
@@ -2323,11 +2323,11 @@ __device__ __forceinline__ void pt_shade_entry(const PtSceneDev& sc, const PtQue
           bool scatter_ok = true;
           if (sc_kind == 2) {
             /* Pdf.sample / Pdf.eval (pdf.ml:5-15, shader_space.ml:56-64) */
-            const double r = pt_sqrt(su);
+            const double r = pt_sqrt_nonneg(su);
             const double theta = sv * 2.0 * pi;
             double sn, cs;
             pt_sincos(theta, &sn, &cs);
-            wo = v3(r * cs, r * sn, pt_sqrt(1.0 - su));
+            wo = v3(r * cs, r * sn, pt_sqrt_nonneg(1.0 - su));
             const double diffuse_pd = (wo.z < 0.0) ? 0.0 : wo.z / pi;
             if (diffuse_pd == 0.0) {
               scatter_ok = false;
@@ -3189,6 +3189,12 @@ __global__ void k_math_eval(int fn, long long n, const double* __restrict__ a, c
     case 6: r = pt_sqrt(x); break;
     case 7: r = x / y; break;
     case 8: r = pt_fma(x, y, y); break;
+    case 9: r = pt_rnorm3(x, y, x - y); break;             /* the fused forms against the oracle's nested literal ones */
+    case 10: r = pt_rnorm_frame(1.0 + x, y, x - y); break;
+    case 11: r = pt_sqrt_nonneg(x); break;
+    case 12: r = pt_rcp_mid(x); break;                     /* mid-range operands only (pt_math.h) */
+    case 13: r = pt_div_mid(x, y); break;
+    case 14: r = pt_sqrt_mid(x); break;
     default: r = pt_nan(); break;
   }
   out[i] = r;
@@ -3201,6 +3207,8 @@ __global__ void k_load_rays(long long n, const double* __restrict__ o, const dou
   pt_q_store_ray(q, (uint32_t)i, v3(o[3 * i], o[3 * i + 1], o[3 * i + 2]), v3(d[3 * i], d[3 * i + 1], d[3 * i + 2]));
 }
 
+#ifndef PT_KERNELS_ONLY /* (tools/quick_kernel.sh instantiates single kernels of this file for register / ISA studies) */
 #include "bvh_build_gpu.inc"
 #include "ppm.inc"
 #include "ptx_api.inc"
+#endif

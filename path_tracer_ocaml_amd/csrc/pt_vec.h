@@ -38,8 +38,7 @@ PT_HD double v3_quadrance(V3 v) { return v3_dot(v, v); }
 PT_HD V3 v3_lerp(double t, V3 v, V3 w) { return v3_add(v3_scale(v, 1.0 - t), v3_scale(w, t)); }
 /* V3.normalize (affine.ml:65-68): scale v (1 / hypot x (hypot y z)) */
 PT_HD V3 v3_normalize(V3 v) {
-  double scalar = 1.0 / pt_hypot(v.x, pt_hypot(v.y, v.z));
-  return v3_scale(v, scalar);
+  return v3_scale(v, pt_rnorm3(v.x, v.y, v.z));
 }
 /* V3.cross (affine.ml:70-73): h w x y z = fma w x (-(y*z)) */
 PT_HD double v3_cross_h(double w, double x, double y, double z) { return pt_fma(w, x, -(y * z)); }

@@ -36,12 +36,57 @@ def shirley(P, oracle):
 
 
 # ---------------------------------------------------------------- shared math: device == host, bit for bit
-@pytest.mark.parametrize("fn", ["hypot", "sin", "cos", "acos", "atan2", "pow5", "sqrt", "div", "fma"])
+MATH_SEED = {"hypot": 1, "sin": 2, "cos": 3, "acos": 4, "atan2": 5, "pow5": 6, "sqrt": 7, "div": 8, "fma": 9, "rnorm3": 10,
+             "rnorm_frame": 11, "sqrt_nonneg": 12, "rcp_mid": 13, "div_mid": 14, "sqrt_mid": 15}
+
+
+@pytest.mark.parametrize("fn", list(MATH_SEED))
 def test_math_device_equals_host_bitwise(P, oracle, fn):
-    rng = np.random.default_rng(hash(fn) % 2**32)
+    """pt_math.h on gfx950 against the same source on x86-64, 2^20 inputs per function.  The fused / bare forms the device
+    takes on its main paths (round 4: pt_rnorm3, pt_rnorm_frame, pt_sqrt_mid, pt_rcp_mid, pt_div_mid -- v_rsq / v_rcp
+    refinement sequences without operand scaling) are compared with what the ORACLE computes for the same expression:
+    the nested literal `1 / hypot x (hypot y z)` through pt_hypot, the IEEE sqrt and division."""
+    rng = np.random.default_rng(MATH_SEED[fn])
     n = 1 << 20
-    if fn in ("sin", "cos"):
-        a = np.concatenate([rng.uniform(0, 2 * np.pi, n // 2), rng.uniform(-1e5, 1e5, n // 2)])
+    if fn in ("rnorm3", "rnorm_frame"):
+        # unit-ish components, scene-scale offsets, exact zeros (axis-aligned normals), far ends of the exponent range
+        a = rng.uniform(-4, 4, n) * 10.0 ** rng.integers(-3, 4, n)
+        b = rng.uniform(-4, 4, n) * 10.0 ** rng.integers(-3, 4, n)
+        if fn == "rnorm_frame":
+            a = rng.uniform(-1, 1, n)
+            b = rng.uniform(-1, 1, n)
+        k = n // 8
+        a[:k] = 0.0
+        b[k:2 * k] = 0.0
+        b[2 * k:3 * k] = a[2 * k:3 * k]  # z = x - y = 0
+        a[3 * k:4 * k] *= 10.0 ** rng.integers(-320, 300, k)
+        b[3 * k:4 * k] *= 10.0 ** rng.integers(-320, 300, k)
+        s = 10.0 ** rng.integers(-300, 300, k)
+        a[4 * k:5 * k] *= s
+        b[4 * k:5 * k] *= s
+        a[5 * k:5 * k + 4] = [np.inf, np.nan, 0.0, -0.0]
+        b[5 * k:5 * k + 4] = [1.0, 1.0, 0.0, 0.0]
+    elif fn in ("sqrt_nonneg",):
+        a = np.concatenate([rng.uniform(0, 1, n // 2), 10.0 ** rng.uniform(-320, 300, n // 2 - 4), [0.0, -0.0, -1.0, np.inf]])
+        b = None
+    elif fn in ("sqrt_mid",):
+        a = np.concatenate([rng.uniform(0, 4, n // 2), 10.0 ** rng.uniform(-225, 225, n // 2)])
+        b = None
+    elif fn in ("rcp_mid", "div_mid"):
+        a = rng.uniform(-4, 4, n) * 10.0 ** rng.uniform(-100, 100, n)
+        b = rng.uniform(-4, 4, n) * 10.0 ** rng.uniform(-100, 100, n)
+        a[a == 0] = 1.0
+        b[b == 0] = 1.0
+        if fn == "div_mid":
+            a[:1000] = 0.0  # a zero numerator is within the contract
+            b[1000:2000] = 1.0  # and so is any numerator over 1
+            a[1000:2000] = 10.0 ** rng.uniform(-320, 300, 1000)
+    elif fn in ("sin", "cos"):
+        a = np.concatenate([rng.uniform(0, 2 * np.pi, n // 2), rng.uniform(-1e5, 1e5, n // 4), rng.uniform(-1e7, 1e7, n // 8),
+                            10.0 ** rng.uniform(-300, 300, n // 8)])
+        k = np.arange(1, 4097)  # doubles next to multiples of pi/2: the third piece of the reduction
+        a[:4096] = np.nextafter(k * (np.pi / 2), np.where(k % 2 == 0, 0.0, 1e9))
+        a[4096:8192] = k * (np.pi / 2)
         b = None
     elif fn == "acos":
         a = np.concatenate([rng.uniform(-1, 1, n - 4), [1.0, -1.0, 0.0, 0.5]])
@@ -55,6 +100,17 @@ def test_math_device_equals_host_bitwise(P, oracle, fn):
     else:
         a = rng.uniform(-4, 4, n) * 10.0 ** rng.integers(-3, 4, n)
         b = rng.uniform(-4, 4, n) * 10.0 ** rng.integers(-3, 4, n)
+        if fn in ("hypot", "atan2"):  # the rarely taken paths: zeros, infinities, NaNs, both ends of the exponent range
+            sp = np.array([0.0, -0.0, 1.0, -1.0, np.inf, -np.inf, np.nan, 5e-324, -5e-324, 1e-310, 1e-300, 1e300, -1e300, 1.7e308,
+                           2.0 ** -250, 2.0 ** 250, 2.0 ** -61, 3.0, 0.4375, 0.6875])
+            g = np.array(np.meshgrid(sp, sp)).reshape(2, -1)
+            a[:g.shape[1]], b[:g.shape[1]] = g[0], g[1]
+            k = n // 8
+            a[k:2 * k] *= 10.0 ** rng.integers(-320, 300, k)
+            b[k:2 * k] *= 10.0 ** rng.integers(-320, 300, k)
+            s = 10.0 ** rng.integers(-300, 300, k)
+            a[2 * k:3 * k] *= s
+            b[2 * k:3 * k] *= s
     dev = P.math_eval(fn, a, b)
     host = oracle.math_vec(P.MATH_FN[fn], a, b)
     same = bits(dev) == bits(host)
