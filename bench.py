@@ -49,7 +49,7 @@ def build_scene(H, name, w, h):
     if name == "shirley":
         return H.shirley_spheres(w, h)
     if name == "cornell":
-        return H.cornell_box(w, h, 12.0)
+        return H.cornell_box(w, h, float(os.environ.get("PTX_BENCH_CORNELL_EMIT", "12.0")))  # 0: no emitter -- same paths, no emission records (a bandwidth A/B)
     if name == "ganesha":
         return H.ganesha_like(w, h, 150000, 7)
     raise ValueError(name)
@@ -175,21 +175,108 @@ def real_reference(workload):
         return {"value": None, "why": f"{type(e).__name__}: {e}"}
 
 
+# The other single-GPU BASELINE configurations, timed by the driver's own command (`workloads` in the JSON line): name -> (workload,
+# band_first, band_step).  Config 5 needs 8 GPUs as a whole; what one GPU can time of it is the busiest rank's share
+# (rank 0 of the 8-rank band deal: 272 of 2160 rows, tools/band_share_timing.py).
+EXTRA_WORKLOADS = {
+    "shirley_600x300_spp32_d8": ("shirley_600x300_spp32_d8", 0, 0),
+    "cornell_1024_spp256_d16": ("cornell_1024_spp256_d16", 0, 0),
+    "ganesha_1080p_spp64_d8": ("ganesha_1080p_spp64_d8", 0, 0),
+    "shirley_4k_spp256_d8_share_1_of_8": ("shirley_4k_spp256_d8", 0, 8),
+}
+
+
+def measure_extra_workload(torch, P, H, D, dev, local_dev, name, steps=3, warmup=1, parity_pixels=64):
+    """One more BASELINE configuration inside the headline run: `warmup` + `steps` queued frames exactly like the headline's
+    (render of the band share + banded film, framebuffer left on the device), one untimed one-stream pass with every launch
+    bracketed by HIP events (the dominant kernel's time), the tracked counter bytes of a step against the step as timed, and
+    -- the oracle as the checker, untimed -- the frame's raw sums of `parity_pixels` whole pixels against the CPU oracle in libm
+    math (the reference's), relative L-inf of the per-pixel mean radiance."""
+    import numpy as np
+    workload, band_first, band_step = EXTRA_WORKLOADS[name]
+    scene_name, w, h, spp, depth = WORKLOADS[workload]
+    world = max(band_step, 1)
+    hs = build_scene(H, scene_name, w, h)
+    scene = P.Scene(hs.ptr, local_dev, keepalive=hs)
+    try:
+        params = P.render_params(w, h, spp, depth, band_rows=D.BAND_ROWS, band_first=band_first, band_step=band_step, asynchronous=True)
+        bg = D.BandGather(h, w, band_first, world, dev)
+        rgb = torch.zeros((h, w, 3), dtype=torch.float64, device=dev)
+        stream = torch.cuda.current_stream().cuda_stream
+        rows = P.local_rows(params)
+
+        def step():
+            scene.render_raw_device(params, bg.part.data_ptr(), stream)
+            P.film_resolve_banded_device(local_dev, w, h, spp, bg.gathered.data_ptr(), world, D.BAND_ROWS, bg.pad_rows, rgb.data_ptr(), stream, wait=False)
+
+        for _ in range(warmup):
+            step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / steps * 1e3
+        samples = rows * w * spp
+        tparams = P.render_params(w, h, spp, depth, band_rows=D.BAND_ROWS, band_first=band_first, band_step=band_step, time_kernels=True)
+        prev = os.environ.get("PTX_STREAMS")
+        os.environ["PTX_STREAMS"] = "1"
+        try:
+            st1 = scene.render_raw_device(tparams, bg.part.data_ptr(), stream)
+        finally:
+            if prev is None:
+                del os.environ["PTX_STREAMS"]
+            else:
+                os.environ["PTX_STREAMS"] = prev
+        kms = {k: v for k, v in st1["kernel_ms"].items() if v}
+        dom = max(kms, key=kms.get) if kms else None
+        tc = tracked_counters(workload) or {}
+        hb = tc.get("hbm_bytes_per_step") if band_step <= 1 else None  # the tracked profile is of the whole frame
+        res = {"workload": workload, "rows": rows, "of_rows": h, "band_step": band_step, "samples_per_step": samples, "steps": steps,
+               "warmup": warmup, "ms_per_step": ms, "value": samples / ms * 1e-3, "unit": "Msamples/s",
+               "dominant_kernel": {"bounce": "k_bounce", "trace": "k_trace", "shade": "k_shade_pool"}.get(dom, dom),
+               "dominant_kernel_ms_one_stream": kms.get(dom), "kernel_ms_one_stream": kms,
+               "hbm_frame": {"traffic_per_step": hb, "achieved": hb / (ms * 1e-3) * 1e-9, "unit": "GB/s", "frac": hb / (ms * 1e-3) * 1e-9 / HBM_PEAK_GBS,
+                             "source": tc.get("source")} if hb else None}
+        try:
+            from oracle import oracle as O
+            od = {"shirley": lambda: O.desc_shirley(w, h), "cornell": lambda: O.desc_cornell(w, h, 12.0),
+                  "ganesha": lambda: O.desc_ganesha_like(w, h, 150000, 7)}[scene_name]()
+            rng = np.random.default_rng(20)
+            lr = rng.integers(0, rows, parity_pixels)            # local rows of the share
+            px = rng.integers(0, w, parity_pixels)
+            py = np.array([P.global_row(params, int(r)) for r in lr])
+            xs, ys, ps = np.repeat(px, spp), np.repeat(py, spp), np.tile(np.arange(spp), parity_pixels)
+            O.set_math(1)
+            try:
+                o_rgb, _ = O.Scene(od.ptr, od).trace_samples(w, h, spp, depth, xs, ys, ps)
+            finally:
+                O.set_math(0)
+            want = o_rgb.reshape(parity_pixels, spp, 3).sum(axis=1) / spp
+            got = bg.part[:rows].cpu().numpy()[lr, px] / spp
+            res["parity"] = {"rel_linf_vs_cpu_ref": float(np.max(np.abs(got - want) / np.maximum(np.abs(want), 1e-3))), "tolerance": 1e-5,
+                             "pixels": parity_pixels, "note": "mean radiance of whole pixels of the timed frame vs the CPU oracle (libm math), untimed"}
+        except Exception as e:
+            res["parity"] = {"rel_linf_vs_cpu_ref": None, "note": f"unavailable: {e}"}
+        return res
+    finally:
+        scene.close()
+
+
 def launch_ranks(n, argv):
     """One process per GPU, exactly as the driver launches them: `python -m torch.distributed.run --nnodes=1
-    --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py <argv>`, as a child of this process.  The
+    --nproc-per-node N ... bench.py <argv>` (here with `--standalone --local-addr 127.0.0.1` instead of a fixed master port),
+    as a child of this process.  The
     parent imports neither torch nor the library, so no GPU state exists here; it relays the child's output (rank 0
     prints the one JSON line) and returns its exit code."""
-    import socket
     import subprocess
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     env.setdefault("OMP_NUM_THREADS", "1")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    # --standalone: the launcher picks (and holds) a free rendezvous port itself -- choosing one here by bind-then-close could
+    # lose it to another job on a shared node between the close and the launcher's bind
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--nnodes=1", f"--nproc-per-node={n}", "--local-addr", "127.0.0.1",
+           os.path.abspath(__file__)] + list(argv)
     return subprocess.run(cmd, env=env).returncode
 
 
@@ -234,6 +321,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="shirley_1080p_spp64_d8", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-workloads", action="store_true",
+                    help="skip the `workloads` block (the other single-GPU BASELINE configurations, 3 timed steps each, added to the headline run at N = 1)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--passes-per-batch", type=int, default=0)
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
@@ -385,15 +474,18 @@ def main():
         hbm_block["frac"] = (hbm_block["achieved"] / hbm_block["peak"]) if hbm_block["achieved"] else None
         if in_lds:
             # tree + packets are LDS-resident: node / slot reads never reach HBM, the binding pipe is vector issue
-            roofline = {"bound": "valu_f64", "kernel": "k_bounce (walk + shade of a bounce in one launch)" if fused else "k_trace", "achieved": flops_achieved, "peak": F64_VECTOR_PEAK_TFLOPS * world,
-                        "unit": "TFLOP/s", "frac": flops_achieved / (F64_VECTOR_PEAK_TFLOPS * world), "traffic": traffic,
-                        "algorithmic_flop_per_launch": alg_flop / n_launch,
+            # `achieved` / `frac` price COUNTED work only: the walk's flops (node tests and packet slots counted by the kernels and
+            # equal to the oracle's).  k_bounce also shades in the same launch; that arithmetic is an estimate per segment and is
+            # reported beside it (incl_estimated_shade), not inside the figure people compare across rounds.
+            walk_achieved = walk_flop / (trace_ms_step * 1e-3) * 1e-12 if trace_ms_step > 0 else 0.0
+            roofline = {"bound": "valu_f64", "kernel": "k_bounce (walk + shade of a bounce in one launch)" if fused else "k_trace", "achieved": walk_achieved, "peak": F64_VECTOR_PEAK_TFLOPS * world,
+                        "unit": "TFLOP/s", "frac": walk_achieved / (F64_VECTOR_PEAK_TFLOPS * world), "traffic": traffic,
+                        "incl_estimated_shade": {"achieved": flops_achieved, "frac": flops_achieved / (F64_VECTOR_PEAK_TFLOPS * world),
+                                                 "note": f"+ {FLOP_PER_SEGMENT_SHADE:g} flop per segment shaded, a hand estimate of the reference's arithmetic outside Scene.intersect"} if fused else None,
+                        "algorithmic_flop_per_launch": walk_flop / n_launch,
                         "flop_model": f"{FLOP_PER_NODE_TEST:g} per Bbox.is_hit + {FLOP_PER_SLOT_SCAN:g} per packet slot scanned (reference arithmetic, binary64)"
-                                      + (f" + {FLOP_PER_SEGMENT_SHADE:g} per segment shaded (approximate)" if fused else ""),
+                                      ,
                         "algorithmic_flop_per_step": {"walk": walk_flop, "shade": shade_flop},
-                        "walk_only": {"achieved": walk_flop / (trace_ms_step * 1e-3) * 1e-12 if trace_ms_step > 0 else 0.0,
-                                      "frac": walk_flop / (trace_ms_step * 1e-3) * 1e-12 / (F64_VECTOR_PEAK_TFLOPS * world) if trace_ms_step > 0 else 0.0,
-                                      "note": "the walk's flops alone over the same kernel time: the figure earlier rounds quoted for k_trace, now over a kernel that also shades"} if fused else None,
                         "issue": {k: tc.get(k) for k in ("valu_busy", "valu_issue_from_insts", "lane_util", "useful_issue_frac", "lds_busy", "lds_bank_conflict_share", "duration_cycles_source", "source")},
                         "hbm": hbm_block}
         else:
@@ -497,6 +589,17 @@ def main():
             except Exception as e:  # the oracle is test infrastructure; its absence must not hide the GPU number
                 out["cpu_baseline"] = {"value": None, "unit": "Msamples/s", "cores": effective_cpus(), "kind": "port",
                                        "sample": f"unavailable: {e}"}
+        if world == 1 and args.workload == "shirley_1080p_spp64_d8" and not args.no_workloads:
+            # the headline fields above are final; the other configurations are measured after them, on the same box
+            out["workloads"] = {}
+            scene.close()
+            del bg, part, rgb
+            torch.cuda.empty_cache()
+            for name in EXTRA_WORKLOADS:
+                try:
+                    out["workloads"][name] = measure_extra_workload(torch, P, H, D, dev, local_dev, name)
+                except Exception as e:
+                    out["workloads"][name] = {"value": None, "error": f"{type(e).__name__}: {e}"}
         print(json.dumps(out))
     if world > 1:
         dist.barrier()

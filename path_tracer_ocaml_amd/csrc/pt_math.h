@@ -204,7 +204,9 @@ PT_HD double pt_hypot(double x, double y) {
 }
 /* 1 / hypot x (hypot y z): the scalar of V3.normalize (affine.ml:65-68), one range test for the whole expression.
  * An inner hypot far below the range cannot change the outer one (x then carries the whole sum), so it is replaced by
- * its larger operand instead of leaving the main path -- axis-aligned normals (y = z = 0) stay on it. */
+ * its larger operand instead of leaving the main path -- axis-aligned normals (y = z = 0) stay on it.  Equal, bit for bit, to
+ * the nested expression evaluated call by call through pt_hypot for every operand triple whose inner hypot is a normal number
+ * (tests/test_math.py); with SUBNORMAL operands the nested form rounds the inner hypot to the subnormal grid first. */
 PT_HD double pt_rnorm3(double x, double y, double z) {
   double ax = pt_fabs(x), ay = pt_fabs(y), az = pt_fabs(z);
   const double sum = (ax + ay) + az;

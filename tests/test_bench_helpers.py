@@ -5,6 +5,8 @@ import os
 import subprocess
 import sys
 
+import pytest
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
@@ -62,20 +64,21 @@ def _json_lines(text):
     return out
 
 
-def test_bench_starts_its_own_ranks():
-    """`python bench.py --gpus 2` with no launcher: the parent starts two fresh ranks through torch.distributed.run before
-    touching any GPU, relays rank 0's ONE JSON line and the exit code.  The rehearsal flag replaces the renderer (which
+@pytest.mark.parametrize("world,workload", [(2, "shirley_600x300_spp32_d8"), (8, "shirley_1080p_spp64_d8")])
+def test_bench_starts_its_own_ranks(world, workload):
+    """`python bench.py --gpus N` with no launcher (N = 8 on the headline frame is what the driver's scaling run starts
+    first): the parent starts N fresh ranks through torch.distributed.run before touching any GPU, relays rank 0's ONE JSON line and the exit code.  The rehearsal flag replaces the renderer (which
     needs a GPU) by synthetic bands, so the launcher, the rendezvous and the band exchange run here on CPU."""
     env = dict(os.environ)
     env.pop("WORLD_SIZE", None)
     env.pop("RANK", None)
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--rehearse-launch",
-                        "--steps", "2", "--warmup", "1", "--workload", "shirley_600x300_spp32_d8"],
-                       capture_output=True, text=True, env=env, timeout=300)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--backend", "gloo", "--rehearse-launch",
+                        "--steps", "2", "--warmup", "1", "--workload", workload],
+                       capture_output=True, text=True, env=env, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = _json_lines(r.stdout)
     assert len(lines) == 1, r.stdout
-    assert lines[0]["n_gpus"] == 2 and lines[0]["steps"] == 2 and lines[0]["warmup"] == 1
+    assert lines[0]["n_gpus"] == world and lines[0]["steps"] == 2 and lines[0]["warmup"] == 1
     assert lines[0]["value"] is None and lines[0]["rehearsal"]["bands_arrived_in_place"] is True
 
 

@@ -41,6 +41,23 @@ def _assemble(P, torch, scene, w, h, spp, depth, world, **kw):
     return full, tot
 
 
+def _frame_pixels_against_the_oracle(oracle, od, scene, raw, w, h, spp, depth, seed, n_px=24):
+    """Whole pixels of the FRAME against the oracle: every pass of n_px pixels traced one by one on the CPU, summed in pass order
+    like render_tile's pass loop (integrator.ml:91-112), compared bit for bit with the frame's raw sums -- the frame itself
+    (all its batches, both streams, 10^8 paths), not the list-mode entry point."""
+    rng = np.random.default_rng(seed)
+    px, py = rng.integers(0, w, n_px), rng.integers(0, h, n_px)
+    xs, ys, ps = np.repeat(px, spp), np.repeat(py, spp), np.tile(np.arange(spp), n_px)
+    o_rgb, _ = oracle.Scene(od.ptr, od).trace_samples(w, h, spp, depth, xs, ys, ps)
+    per = o_rgb.reshape(n_px, spp, 3)
+    sums = np.zeros((n_px, 3))
+    for k in range(spp):
+        sums = sums + per[:, k, :]
+    got = raw.cpu().numpy()[py, px]
+    assert np.array_equal(sums.view(np.uint64), got.view(np.uint64)), "frame raw sums != oracle per-sample sums in pass order"
+    assert float(np.abs(sums).max()) > 0.0
+
+
 def test_config2_shirley_1080p_spp64(P, oracle):
     torch = pytest.importorskip("torch")
     from path_tracer_ocaml_amd import host as H
@@ -99,6 +116,7 @@ def test_config3_cornell_1024_spp256_depth16(P, oracle):
     g_rgb, g_st = scene.trace_samples(w, h, spp, depth, xs, ys, ps, count_work=True)
     assert np.array_equal(g_rgb.view(np.uint64), o_rgb.view(np.uint64))
     assert g_st["nodes_tested"] == o_ct["nodes_tested"] and g_st["prims_tested"] == o_ct["prims_tested"]
+    _frame_pixels_against_the_oracle(oracle, od, scene, a, w, h, spp, depth, seed=16)  # 24 x 256 samples at depth 16
     scene.close()
 
 
@@ -121,6 +139,7 @@ def test_config4_ganesha_like_150k_triangles(P, oracle):
     assert np.array_equal(g_rgb.view(np.uint64), o_rgb.view(np.uint64))
     for k in ("segments", "nodes_tested", "prims_tested", "floor_tested"):
         assert g_st[k] == o_ct[k], k
+    _frame_pixels_against_the_oracle(oracle, od, scene, a, w, h, spp, depth, seed=17, n_px=48)
     scene.close()
 
 

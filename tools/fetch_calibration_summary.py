@@ -32,6 +32,7 @@ prog = json.load(open(os.path.join(out, "fetch_calib.json")))
 fetch, nf = counters("pmc_fetch")
 rd, nr = counters("pmc_rdreq")
 tcc, nt = counters("pmc_tcc")
+sz, ns = counters("pmc_sizes")
 rows = []
 for r in prog["rows"]:
     k = r["kernel"]
@@ -45,6 +46,14 @@ for r in prog["rows"]:
     if k in rd:
         for c in rd[k]:
             e[c + "_per_record"] = rd[k][c] / nr[k][c] / r["records"]
+    if k in sz:
+        for c in sz[k]:
+            e[c + "_per_record"] = sz[k][c] / ns[k][c] / r["records"]
+        if "TCC_EA0_RDREQ_128B_sum" in sz[k] and "TCC_EA0_RDREQ_64B_sum" in sz[k]:
+            b128 = sz[k]["TCC_EA0_RDREQ_128B_sum"] / ns[k]["TCC_EA0_RDREQ_128B_sum"]
+            b64 = sz[k]["TCC_EA0_RDREQ_64B_sum"] / ns[k]["TCC_EA0_RDREQ_64B_sum"]
+            e["sized_request_bytes"] = 128.0 * b128 + 64.0 * b64  # + 32 B requests: none on any shape here
+            e["sized_request_bytes_per_requested"] = e["sized_request_bytes"] / r["requested_bytes"]
     if k in tcc:
         for c in tcc[k]:
             e[c + "_per_record"] = tcc[k][c] / nt[k][c] / r["records"]
@@ -55,9 +64,10 @@ res = {"source": out, "buffer_bytes": prog["buffer_bytes"],
 path = os.path.join(root, "profiles", f"{tag}_fetch_calibration.json")
 json.dump(res, open(path, "w"), indent=1)
 for e in rows:
-    print("%-22s %-7s rec %3d: requested %7.1f MB  %7.1f GB/s  FETCH_SIZE/requested %s  per record %s B  %s" % (
+    print("%-22s %-7s rec %3d: requested %7.1f MB  %7.1f GB/s  FETCH_SIZE/requested %s  sized/requested %s  per record %s B  %s" % (
         e["kernel"], e["pattern"], e["record_bytes"], e["requested_bytes"] * 1e-6, e["requested_gbs"],
         "%.3f" % e["fetch_size_per_requested"] if "fetch_size_per_requested" in e else "-",
+        "%.3f" % e["sized_request_bytes_per_requested"] if "sized_request_bytes_per_requested" in e else "-",
         "%.1f" % e["fetch_size_per_record"] if "fetch_size_per_record" in e else "-",
         {c: round(v, 3) for c, v in e.items() if c.endswith("_per_record") and c != "fetch_size_per_record"}))
 print("->", path)
