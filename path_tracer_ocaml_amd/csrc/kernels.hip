@@ -381,18 +381,29 @@ typedef unsigned int pt_u2 __attribute__((ext_vector_type(2), aligned(4)));
 #define PT_SWZ_END 0xffffu
 /* bytes of LDS a wave keeps for traversal stacks: LDS-resident scenes walk the threaded image (no per-lane stack) and
  * only the camera-ray packet walk keeps its shared (node, mask) stack there: 12 bytes per level, rounded to 16 */
-#define PT_WAVE_STACK_BYTES(LDS_SCENE, StackT, depth) ((LDS_SCENE) ? (size_t)(depth) * 16u : (std::is_same<StackT, PtThreadTag>::value ? (size_t)0 : (size_t)(depth) * PT_WAVE * sizeof(StackT)))
+#define PT_WAVE_STACK_BYTES(LDS_SCENE, StackT, depth) ((LDS_SCENE) ? (size_t)(depth) * 16u : ((std::is_same<StackT, PtThreadTag>::value || std::is_same<StackT, PtThreadOctTag>::value) ? (size_t)0 : (size_t)(depth) * PT_WAVE * sizeof(StackT)))
 
 /* where the traversal data of this launch lives: HBM/L2 (large scenes) or an LDS copy (small scenes) */
 /* StackT of a walk that needs no stack: scenes traversed from HBM / L2 follow per-octant skip links like the LDS image
  * does (PtSceneDev.node_skip32), which frees the LDS the per-lane stacks took (depth x 256 bytes per wave: it capped
  * the ganesha-like scene at 3 waves per SIMD where its registers allow 4) */
 struct PtThreadTag {};
+/* ... and the same walk on the PER-OCTANT node image (PtSceneDev.nodes32o): one 32-byte record per (direction octant, node) that
+ * carries the six binary32 bounds, ONE link word and the skip link of that octant -- a visit is two 16-byte loads instead of
+ * two + the skip table's entry.  The texture-address unit that binds the walk from HBM / L2 works per load instruction and
+ * lane (profiles/r03c_ganesha_ta_tcp.txt: three per node test); the price is eight copies of the bounds (23 MB for 92 k nodes
+ * instead of 6 MB of image + table).  A pre-order tree needs no lhs link (the lhs child of node k is k + 1), which is what
+ * frees the word: inner nodes keep `rhs | axis << 30`, leaves pack `tag << 30 | real slots << 22 | first slot`. */
+struct PtThreadOctTag {};
+#define PT_OCT_LEAF_FIRST_BITS 22
+#define PT_OCT_LEAF_REAL_MAX 255u
 
 struct PtSceneView {
   const PtNode* nodes;
   const uint32_t* skip32; /* threaded global walk: n_nodes x 8, 0xffffffff = none */
   const unsigned char* nodes32; /* 32-byte binary32 image of the nodes for the walk from HBM / L2 */
+  const unsigned char* nodes32o; /* ... per direction octant (PtThreadOctTag), 8 x n_nodes x 32 bytes, or null */
+  uint32_t n_nodes;
   const unsigned char* swz_nodes; /* LDS-resident scenes: the binary32 filter image, PT_SWZ_NODE_BYTES per node */
   uint32_t swz_root;              /* what the walk's `node` is for node 0: 0 (byte offsets into the image) or, with PT_SWZ_SIGNSEL, the
                                      image's absolute LDS address */
@@ -402,7 +413,14 @@ struct PtSceneView {
   const double* sph;
   const double* tri;
   const uint8_t* kind;
+  /* scenes walked from HBM / L2: the first n_floor_lds floor triangles (ganesha's Floor, tested before the tree for EVERY ray,
+   * main.ml:247-256) as 10-double records in LDS.  Read from global memory their 2 x 5 loads per ray were a fifth of the
+   * walk's vector-memory instructions -- all lanes at the same address, but the texture-address unit that binds this kernel
+   * still processes every one of them; an LDS read of one address is a broadcast on a pipe the kernel does not use. */
+  const __attribute__((address_space(3))) double* floor_lds;
+  int n_floor_lds;
 };
+#define PT_FLOOR_LDS 4
 
 struct PtTraceResult {
   double t, u, v;
@@ -417,6 +435,8 @@ template <class T> __device__ __forceinline__ void pt_stack_push(T* stk, int sp,
 template <class T> __device__ __forceinline__ uint32_t pt_stack_pop(const T* stk, int sp) { return (uint32_t)stk[sp * PT_WAVE]; }
 __device__ __forceinline__ void pt_stack_push(PtThreadTag*, int, uint32_t) {}
 __device__ __forceinline__ uint32_t pt_stack_pop(const PtThreadTag*, int) { return 0u; }
+__device__ __forceinline__ void pt_stack_push(PtThreadOctTag*, int, uint32_t) {}
+__device__ __forceinline__ uint32_t pt_stack_pop(const PtThreadOctTag*, int) { return 0u; }
 #define PT_STACK_PUSH(stk, sp, val) pt_stack_push((stk), (sp), (uint32_t)(val))
 #define PT_STACK_POP(stk, sp) pt_stack_pop((stk), (sp))
 
@@ -455,14 +475,16 @@ __device__ __forceinline__ uint32_t pt_stack_pop(const PtThreadTag*, int) { retu
 template <int MODE, bool COUNT, bool ORIGIN_ZERO, typename StackT, bool SWZ>
 struct PtTraverser {
   /* the binary32 filter runs wherever the walk is threaded: on the LDS image (SWZ) and on the 32-byte global image */
-  static constexpr bool G32 = !SWZ && std::is_same<StackT, PtThreadTag>::value;
+  static constexpr bool OCT = !SWZ && std::is_same<StackT, PtThreadOctTag>::value; /* the per-octant image (PtThreadOctTag) */
+  static constexpr bool G32 = !SWZ && (std::is_same<StackT, PtThreadTag>::value || OCT);
   static constexpr bool FILT = SWZ || G32;
   V3 o, d, inv; /* SWZ: inv is not kept (the binary64 fallback recomputes 1 / d, the same three divisions) */
   uint32_t dirs;
   bool exact_slab; /* SWZ: also set when the binary32 filter does not apply to this ray (|1/d| >= 2^100) */
   /* binary32 filter constants of the ray (SWZ only): inv32, -(o * inv)32, k2 = 2^-19 max|inv|, c2 = max|o| k2 + 2^-21 t32 */
   float fix, fiy, fiz, fnx, fny, fnz, k2, c2base, c2, t32;
-  uint32_t skip_off; /* SWZ: byte offset of this ray's octant entry in a node's skip table */
+  uint32_t skip_off; /* SWZ: byte offset of this ray's octant entry in a node's skip table; OCT: index of the octant's node 0 */
+  mutable uint32_t oct_skip; /* OCT: the visited node's skip link, out of its record (test_box) */
   uint32_t sel_x, sel_y, sel_z; /* PT_SWZ_SIGNSEL: byte offsets of the ray's (near, far) bound pairs */
   mutable unsigned long long n_undecided = 0, n_wave_fallbacks = 0; /* COUNT only (ptx_stats.filter_*) */
   double qa, one_over_a;
@@ -557,11 +579,21 @@ struct PtTraverser {
     /* ganesha Floor.intersect (main.ml:247-256): f1 then f2, the first hit clips t_max for the tree */
     if (MODE == PT_MODE_ARRAY && sc.n_floor > 0) {
       for (int f = 0; f < sc.n_floor; ++f) {
-        const double* tv = sv.tri + (size_t)(sc.n_slots + f) * 10;
+        V3 fa, fb, fc;
+        if (f < sv.n_floor_lds) { /* (wave-uniform) */
+          const __attribute__((address_space(3))) double* tv = sv.floor_lds + f * 10;
+          fa = v3(tv[0], tv[1], tv[2]);
+          fb = v3(tv[3], tv[4], tv[5]);
+          fc = v3(tv[6], tv[7], tv[8]);
+        } else {
+          const double* tv = sv.tri + (size_t)(sc.n_slots + f) * 10;
+          fa = pt_load_v3(tv);
+          fb = pt_load_v3(tv + 3);
+          fc = pt_load_v3(tv + 6);
+        }
         double t, u, v;
         if (COUNT) c_floor++;
-        if (pt_triangle_intersect(pt_load_v3(tv), pt_load_v3(tv + 3), pt_load_v3(tv + 6), o, d, 0.0, PT_MAX_FINITE, &t,
-                                  &u, &v)) {
+        if (pt_triangle_intersect(fa, fb, fc, o, d, 0.0, PT_MAX_FINITE, &t, &u, &v)) {
           r.t = t;
           r.u = u;
           r.v = v;
@@ -578,7 +610,8 @@ struct PtTraverser {
       one_over_a = 1.0 / qa;
     }
     sp = 0;
-    node = SWZ ? sv.swz_root : ((G32 && sv.has_top) ? PT_TOP_FLAG : 0u); /* the root (slot 0 of the top image) */
+    if (OCT) skip_off = dirs * sv.n_nodes;
+    node = SWZ ? sv.swz_root : ((G32 && !OCT && sv.has_top) ? PT_TOP_FLAG : 0u); /* the root (slot 0 of the top image) */
     walking = sc.n_nodes > 0;
     leaf_first = 0;
     leaf_n = 0;
@@ -662,6 +695,19 @@ struct PtTraverser {
         nb = (w1.z >> 16) | ((w1.w & 3u) << 30);
         n_real = w1.z >> 16; /* meaningful for leaves only */
         mag = __uint_as_float(w1.w);
+      } else if (OCT) { /* nd is the node's index; the octant's 32-byte record: six binary32 bounds, link, skip */
+        const uint4* p = (const uint4*)(sv.nodes32o + (size_t)(skip_off + nd) * 32u);
+        w0 = p[0];
+        w1 = p[1];
+        const bool leaf = (w1.z >> 30) == PT_NODE_LEAF_AXIS;
+        n_real = (w1.z >> PT_OCT_LEAF_FIRST_BITS) & PT_OCT_LEAF_REAL_MAX;
+        na = leaf ? (w1.z & ((1u << PT_OCT_LEAF_FIRST_BITS) - 1u)) : nd + 1u; /* pre-order: the lhs child follows its parent */
+        /* (Leaf.length incl. the Simd_leaf padding to a multiple of 4, main.ml:179-186: for the work counter only) */
+        nb = leaf ? ((MODE == PT_MODE_SIMD ? ((n_real + 3u) & ~3u) : n_real) | (PT_NODE_LEAF_AXIS << 30)) : w1.z;
+        oct_skip = w1.w;
+        mag = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(__uint_as_float(w0.x)), __builtin_fabsf(__uint_as_float(w0.y))),
+                                              __builtin_fmaxf(__builtin_fabsf(__uint_as_float(w0.z)), __builtin_fabsf(__uint_as_float(w0.w)))),
+                              __builtin_fmaxf(__builtin_fabsf(__uint_as_float(w1.x)), __builtin_fabsf(__uint_as_float(w1.y)))) * 1.000001f;
       } else { /* nd is the node's index; 32-byte global image: six binary32 bounds, a, b (leaf b: count | real << 15 | tag) */
         if (nd & PT_TOP_FLAG) { /* ... or PT_TOP_FLAG | byte offset into the LDS copy of the tree's top: same words */
           const uint4* p = (const uint4*)(sv.top + (nd & (PT_TOP_FLAG - 1u)));
@@ -719,14 +765,14 @@ struct PtTraverser {
     bool descend = false;
     uint32_t na, nb, n_real;
     /* threaded image: where to go once this subtree is done (issued beside the node's own reads) */
-    constexpr bool THREAD32 = !SWZ && std::is_same<StackT, PtThreadTag>::value;
+    constexpr bool THREAD32 = G32;
     uint32_t skip;
 #if PT_SWZ_SIGNSEL
     if (SWZ) skip = (uint32_t)*(const __attribute__((address_space(3))) uint16_t*)PT_LDS_AT(node + skip_off + PT_SWZ_OFF_SKIP);
 #else
     if (SWZ) skip = (uint32_t)*(const uint16_t*)(sv.swz_nodes + node + skip_off);
 #endif
-    else if (!THREAD32) skip = 0u;
+    else if (!THREAD32 || OCT) skip = 0u; /* OCT: the link arrives with the node's record (test_box) */
     else if (node & PT_TOP_FLAG) { /* top image: 16-bit byte offsets, a top node's successor is a top node */
       const uint32_t s16 = (uint32_t)*(const uint16_t*)(sv.top + (node & (PT_TOP_FLAG - 1u)) + 32u + 2u * dirs);
       skip = s16 == 0xffffu ? 0xffffffffu : (PT_TOP_FLAG | s16);
@@ -753,6 +799,7 @@ struct PtTraverser {
     }
 #endif
     const bool hit = test_box(sv, node, na, nb, n_real);
+    if (OCT) skip = oct_skip;
     if (hit) {
       const uint32_t axis = nb >> 30;
       if (axis == PT_NODE_LEAF_AXIS) {
@@ -1310,10 +1357,14 @@ __device__ __forceinline__ PtSceneView pt_scene_view(const PtSceneDev& sc, unsig
   sv.nodes = sc.nodes;
   sv.skip32 = sc.node_skip32;
   sv.nodes32 = (const unsigned char*)sc.nodes32;
+  sv.nodes32o = (const unsigned char*)sc.nodes32o;
+  sv.n_nodes = (uint32_t)sc.n_nodes;
   sv.swz_nodes = nullptr;
   sv.swz_root = 0u;
   sv.top = lds_raw;
   sv.has_top = false;
+  sv.floor_lds = nullptr;
+  sv.n_floor_lds = 0;
   if (!LDS_SCENE && want_top && sc.n_top > 0) { /* the tree's top into LDS (the caller's barrier follows) */
     const uint4* src = (const uint4*)sc.top_nodes;
     uint4* dst = (uint4*)lds_raw;
@@ -1525,19 +1576,29 @@ __global__ __launch_bounds__(PT_TRACE_BLOCK_OF(MODE, LDS_SCENE), (LDS_SCENE && M
   const int lane = pt_lane();
   const int wave_in_block = (int)(threadIdx.x >> 6);
   /* LDS-resident scenes have < 65536 nodes: 16-bit stack entries halve the stack footprint */
-  typedef typename std::conditional<LDS_SCENE, uint16_t, PtThreadTag>::type StackT; /* no per-lane stack anywhere: both walks are threaded */
+  /* no per-lane stack anywhere: both walks are threaded.  PACKET on a scene walked from HBM / L2 (where wave packets do not
+   * pay) selects the per-octant node image instead (PtThreadOctTag; the host launches it when PtSceneDev.nodes32o exists) */
+  typedef typename std::conditional<LDS_SCENE, uint16_t, typename std::conditional<PACKET, PtThreadOctTag, PtThreadTag>::type>::type StackT;
   StackT* stack = (StackT*)(lds_raw + (size_t)wave_in_block * PT_WAVE_STACK_BYTES(LDS_SCENE, StackT, stack_depth));
   __shared__ uint32_t lds_chunk_ctr;
   if (threadIdx.x == 0) lds_chunk_ctr = 0u;
-  const PtSceneView sv = pt_scene_view<MODE, LDS_SCENE, StackT>(sc, lds_raw, stack_depth, top_in_lds != 0);
-  if (!LDS_SCENE) __syncthreads(); /* pt_scene_view ends with a barrier only when it copies the whole scene */
+  PtSceneView sv = pt_scene_view<MODE, LDS_SCENE, StackT>(sc, lds_raw, stack_depth, top_in_lds != 0);
+  if (!LDS_SCENE) {
+    __shared__ double lds_floor[PT_FLOOR_LDS * 10];
+    if (MODE == PT_MODE_ARRAY && sc.n_floor > 0) { /* the pre-tested floor triangles: see PtSceneView.floor_lds */
+      sv.n_floor_lds = sc.n_floor < PT_FLOOR_LDS ? sc.n_floor : PT_FLOOR_LDS;
+      sv.floor_lds = (const __attribute__((address_space(3))) double*)lds_floor;
+      for (int k = threadIdx.x; k < sv.n_floor_lds * 10; k += blockDim.x) lds_floor[k] = sc.tri[(size_t)sc.n_slots * 10 + k];
+    }
+    __syncthreads(); /* pt_scene_view ends with a barrier only when it copies the whole scene */
+  }
   const uint32_t n = PRIMARY ? n_primary : *q.count;
   PtChunkFeed feed;
   feed.init(work, (uint32_t)(((unsigned long long)n + PT_WAVE - 1) / PT_WAVE), &lds_chunk_ctr);
   uint32_t chunk;
   unsigned long long c_nodes = 0, c_prims = 0, c_floor = 0, c_seg = 0, c_filter[2] = {0, 0};
 
-  if (PACKET) { /* the 64 rays of the wave walk the tree together (pt_trace_packet) */
+  if (PACKET && LDS_SCENE) { /* the 64 rays of the wave walk the tree together (pt_trace_packet) */
     /* the wave's private stack area (stack_depth x 64 entries) holds the shared (node, mask) stack: 12 B per level */
     uint32_t* wstack = (uint32_t*)(lds_raw + (size_t)wave_in_block * PT_WAVE_STACK_BYTES(LDS_SCENE, StackT, stack_depth));
     while (feed.take(chunk)) {

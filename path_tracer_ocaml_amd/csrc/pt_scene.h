@@ -108,6 +108,10 @@ struct PtSceneDev {
   /* n_nodes x 32 bytes: mn.xyz, mx.xyz rounded to binary32, a, b (leaf b: padded count | real count << 15 | tag): the filter
    * image of the walk from HBM / L2 -- half the bytes per visit of the 64-byte binary64 node, which only undecided tests read */
   const void* nodes32;
+  /* 8 x n_nodes x 32 bytes, or NULL: the same image once per direction octant with that octant's skip link inside the record
+   * (mn.xyz, mx.xyz, link, skip) -- a visit is two loads instead of three (kernels.hip, PtThreadOctTag).  Built when the tree
+   * is in pre-order with lhs = node + 1 (always) and every leaf fits the packed link (first slot < 2^22, <= 255 real slots). */
+  const void* nodes32o;
   /* Scenes walked from HBM / L2: the TOP of the tree (the first n_top nodes in breadth-first order) as 64-byte records that
    * every trace workgroup copies into LDS -- 6 binary32 bounds, links a / b as in nodes32, eight 16-bit skip links (byte
    * offsets into this image; the node that follows a top node's subtree is an ancestor's sibling, hence a top node too), the
