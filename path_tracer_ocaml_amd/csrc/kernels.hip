@@ -48,15 +48,23 @@ struct PtQueue {
 struct PtHits {
   double* t;     /* scenes without triangles: t_hit per entry */
   int32_t* slot; /* leaf slot index, -1 = miss; >= n_slots = floor triangle */
-  /* scenes with triangles: ONE 32-byte record {t_hit, u, v, -} per entry (triangle barycentrics, triangle.ml:14-20) instead of
-   * three arrays -- the shade stage gathers an entry's hit sparsely (one category at a time), and three 8-byte reads from three
-   * arrays cost three 32-byte sectors where the record costs one.  `t` is then unused (NULL). */
+  /* scenes with triangles: ONE 32-byte record {t_hit, u, v, -} per entry (triangle barycentrics, triangle.ml:14-20), `t` is
+   * then unused (NULL).  Round 4: only ptx_intersect_rays asks for these records (tuv != NULL).  A render does not keep them
+   * at all: the shade step RECOMPUTES (t, u, v) from the ray and the one primitive that was hit (PT_RECOMPUTE_HIT) -- the
+   * same function on the same operands, so the same bits -- because the record cost a 32-byte write per segment and, gathered
+   * again one or two chunks later when the L2 no longer holds it, a whole 128-byte line of fabric traffic per segment
+   * (cornell's bounce launches, TCC counters: 2.7 line requests per segment reach the L2, 2.4 miss): ~60 vector instructions
+   * against a third of the kernel's memory traffic. */
   double4* tuv;
 };
+#ifndef PT_RECOMPUTE_HIT
+#define PT_RECOMPUTE_HIT 1
+#endif
 __device__ __forceinline__ void pt_hit_store(const PtHits& hits, uint32_t i, double t, int slot, double u, double v, bool with_uv) {
   hits.slot[i] = slot;
-  if (with_uv) hits.tuv[i] = make_double4(t, u, v, 0.0);
-  else hits.t[i] = t;
+  if (with_uv) {
+    if (!PT_RECOMPUTE_HIT || hits.tuv) hits.tuv[i] = make_double4(t, u, v, 0.0);
+  } else hits.t[i] = t;
 }
 
 /* A queue written by k_shade_pool has HOLES (unused entries of its last blocks): direction x = a NaN whose payload no
@@ -2349,13 +2357,27 @@ __device__ __forceinline__ void pt_shade_entry(const PtSceneDev& sc, const PtQue
         PtSlotGeom geom;
         geom.cx = geom.cy = geom.cz = 0.0;
         geom.kind = PT_SLOT_SPHERE;
-        if (sc.has_triangles) { /* one 32-byte record (PtHits) */
-          const double2* hp = (const double2*)(hits.tuv + i);
+        if (sc.has_triangles) {
+          geom.kind = (int)sc.slot_kind[slot];
+#if PT_RECOMPUTE_HIT
+          /* (t, u, v) of the hit again, from the ray and the primitive the walk settled on: Array_leaf's own element tests
+           * (PtTraverser::packet, begin's floor test) on the same operands.  Their acceptance range only ever decided WHICH
+           * primitive won; the values do not depend on it. */
+          t_hit = 0.0;
+          if (geom.kind == PT_SLOT_SPHERE) {
+            const double* sp = sc.sph + (size_t)slot * 4;
+            (void)pt_sphere_intersect_scalar(v3(sp[0], sp[1], sp[2]), sp[3], o, d, 0.0, PT_MAX_FINITE, &t_hit);
+          } else {
+            const double* tvx = sc.tri + (size_t)slot * 10;
+            (void)pt_triangle_intersect(pt_load_v3(tvx), pt_load_v3(tvx + 3), pt_load_v3(tvx + 6), o, d, 0.0, PT_MAX_FINITE, &t_hit, &bu, &bv);
+          }
+#else
+          const double2* hp = (const double2*)(hits.tuv + i); /* one 32-byte record (PtHits) */
           const double2 h0 = hp[0], h1 = hp[1];
           t_hit = h0.x;
           bu = h0.y;
           bv = h1.x;
-          geom.kind = (int)sc.slot_kind[slot];
+#endif
         } else {
           t_hit = hits.t[i];
           const double2* sp = (const double2*)(sc.sph + (size_t)slot * 4);
@@ -2978,8 +3000,9 @@ __global__ __launch_bounds__(PT_BOUNCE_THREADS, PT_BOUNCE_WAVES) void k_bounce(P
     if (done) {
       /* the hit distance (and a triangle's barycentrics) reach the shade step through memory -- this wave's own L1 / L2
        * lines; the slot travels in the pool entry */
-      if (MODE == PT_MODE_ARRAY && sc.has_triangles) hits.tuv[i] = make_double4(r.t, r.u, r.v, 0.0);
-      else hits.t[i] = r.t;
+      if (MODE == PT_MODE_ARRAY && sc.has_triangles) {
+        if (!PT_RECOMPUTE_HIT) hits.tuv[i] = make_double4(r.t, r.u, r.v, 0.0); /* (else the shade step recomputes it: PtHits) */
+      } else hits.t[i] = r.t;
       cat = r.slot < 0 ? PT_CAT_MISS : (int)sc.slot_cat[r.slot];
     }
 #pragma unroll
