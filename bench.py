@@ -546,9 +546,11 @@ def main():
             import numpy as np
             fb = np.zeros((h, w, 3))  # the caller's image, allocated and touched once like the reference's Bimage
             scene.render(w, h, spp, depth, out=fb)
+            scene.render(w, h, spp, depth, out=fb)  # the second render into the same image page-locks it (one-time cost)
             t2 = time.perf_counter()
-            scene.render(w, h, spp, depth, out=fb)
-            host_ms = (time.perf_counter() - t2) * 1e3
+            for _ in range(3):
+                scene.render(w, h, spp, depth, out=fb)
+            host_ms = (time.perf_counter() - t2) * 1e3 / 3
             host_api = {"ptx_render_ms": host_ms, "msamples_per_s": samples / host_ms * 1e-3,
                         "note": "ptx_render: whole frame on this GPU, post-gamma framebuffer copied into the caller's host image (PCIe inclusive: never `value`)"} if world == 1 else None
         except Exception as e:

@@ -62,14 +62,28 @@ typedef struct ptx_ml_flat {
   const int32_t* floor_material;
 } ptx_ml_flat;
 
-/* NULL + ptx_last_error() on failure, like ptx_scene_create.  Nothing of `f` is referenced after the call returns. */
+/* Why the last ptx_ml_scene_create of this thread returned NULL: a message of THIS layer (bad counts, no memory), or NULL when
+ * the library refused the scene and ptx_last_error() holds the reason.  The stub raises ptx_ml_scene_create_error() first. */
+static __thread const char* ptx_ml_create_error_;
+static __attribute__((unused)) const char* ptx_ml_scene_create_error(void) { return ptx_ml_create_error_ ? ptx_ml_create_error_ : ptx_last_error(); }
+
+/* NULL + ptx_ml_scene_create_error() on failure.  Nothing of `f` is referenced after the call returns. */
 static ptx_scene* ptx_ml_scene_create(const ptx_ml_flat* f, int32_t device) {
-  if (!f || f->n_spheres < 0 || f->n_triangles < 0 || f->n_floor_triangles < 0 || f->n_materials <= 0 || f->n_textures < 0) return NULL;
+  ptx_ml_create_error_ = NULL;
+  if (!f || f->n_spheres < 0 || f->n_triangles < 0 || f->n_floor_triangles < 0 || f->n_textures < 0) {
+    ptx_ml_create_error_ = "Ptx.scene_create: negative element count";
+    return NULL;
+  }
+  if (f->n_materials <= 0) {
+    ptx_ml_create_error_ = "Ptx.scene_create: the material table is empty";
+    return NULL;
+  }
   ptx_material* mats = (ptx_material*)calloc((size_t)f->n_materials, sizeof *mats);
   ptx_texture* texs = (ptx_texture*)calloc((size_t)(f->n_textures > 0 ? f->n_textures : 1), sizeof *texs);
   if (!mats || !texs) {
     free(mats);
     free(texs);
+    ptx_ml_create_error_ = "Ptx.scene_create: out of memory for the material / texture tables";
     return NULL;
   }
   for (int32_t i = 0; i < f->n_materials; ++i) {

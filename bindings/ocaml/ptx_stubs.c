@@ -14,7 +14,9 @@
  *                       (the reference reads `coords` the same way: header >> 10 words, lib.rs:26-36)
  *   Bigarray.Array1     Caml_ba_data_val(v), Caml_ba_array_val(v)->dim[0]
  *   int                 Long_val / Val_long
- *   scene handle        custom block holding the ptx_scene*, finalised with ptx_scene_destroy
+ *   scene handle        custom block holding the ptx_scene* and an in-use count, finalised with ptx_scene_destroy.  The count
+ *                       is raised for the duration of a render (which runs with the runtime lock released): Ptx.scene_destroy
+ *                       from another thread or domain meanwhile raises Failure instead of freeing what the render reads
  *   errors              caml_failwith (ptx_last_error ()): no error code ever reaches OCaml unraised
  *   callbacks           update_progress / on_iteration run on the CALLING thread (the library's contract).  The runtime
  *                       lock is RELEASED for the duration of the render (other domains and threads keep running; the
@@ -35,14 +37,29 @@
 
 #include "ptx_ml_marshal.h"
 
-#define Scene_val(v) (*((ptx_scene**)Data_custom_val(v)))
+typedef struct ptx_ml_handle {
+  ptx_scene* scene;
+  int in_use; /* renders running on the scene right now (atomic: OCaml 5 domains run in parallel) */
+} ptx_ml_handle;
+#define Handle_val(v) ((ptx_ml_handle*)Data_custom_val(v))
+#define Scene_val(v) (Handle_val(v)->scene)
 
+/* the finaliser: runs only when nothing reaches the handle any more, so no render can be using it */
 static void ptx_ml_scene_finalize(value v) {
   if (Scene_val(v)) {
     ptx_scene_destroy(Scene_val(v));
     Scene_val(v) = NULL;
   }
 }
+/* a render takes the scene for the time the runtime lock is released; NULL = already destroyed */
+static ptx_scene* ptx_ml_scene_acquire(value handle) {
+  ptx_ml_handle* h = Handle_val(handle);
+  __atomic_add_fetch(&h->in_use, 1, __ATOMIC_ACQ_REL);
+  ptx_scene* s = __atomic_load_n(&h->scene, __ATOMIC_ACQUIRE);
+  if (!s) __atomic_sub_fetch(&h->in_use, 1, __ATOMIC_ACQ_REL);
+  return s;
+}
+static void ptx_ml_scene_release(value handle) { __atomic_sub_fetch(&Handle_val(handle)->in_use, 1, __ATOMIC_ACQ_REL); }
 
 static struct custom_operations ptx_ml_scene_ops = {
     "dalev.path_tracer.ptx_scene", ptx_ml_scene_finalize, custom_compare_default, custom_hash_default,
@@ -117,15 +134,25 @@ CAMLprim value ptx_ml_scene_create_stub(value flat, value device) {
   /* no OCaml allocation between reading the pointers above and the end of ptx_ml_scene_create: nothing can move
    * (the runtime lock stays held here: the floatarrays live in the OCaml heap) */
   ptx_scene* s = ptx_ml_scene_create(&f, (int32_t)Long_val(device));
-  if (!s) caml_failwith(ptx_last_error());
-  handle = caml_alloc_custom(&ptx_ml_scene_ops, sizeof(ptx_scene*), 0, 1);
-  Scene_val(handle) = s;
+  if (!s) caml_failwith(ptx_ml_scene_create_error());
+  handle = caml_alloc_custom(&ptx_ml_scene_ops, sizeof(ptx_ml_handle), 0, 1);
+  Handle_val(handle)->scene = s;
+  Handle_val(handle)->in_use = 0;
   CAMLreturn(handle);
 }
 
 /* external scene_destroy : scene -> unit = "ptx_ml_scene_destroy_stub"   (optional: the finaliser does the same) */
 CAMLprim value ptx_ml_scene_destroy_stub(value handle) {
-  ptx_ml_scene_finalize(handle);
+  ptx_ml_handle* h = Handle_val(handle);
+  /* take the scene out of the handle first, then look at the count: a render that starts after this sees NULL, one that
+   * started before it is counted */
+  ptx_scene* s = __atomic_exchange_n(&h->scene, NULL, __ATOMIC_ACQ_REL);
+  if (!s) return Val_unit;
+  if (__atomic_load_n(&h->in_use, __ATOMIC_ACQUIRE) > 0) {
+    __atomic_store_n(&h->scene, s, __ATOMIC_RELEASE); /* put it back: the finaliser or a later call frees it */
+    caml_failwith("Ptx.scene_destroy: a render is running on this scene");
+  }
+  ptx_scene_destroy(s);
   return Val_unit;
 }
 
@@ -174,10 +201,10 @@ CAMLprim value ptx_ml_render_stub(value handle, value width, value height, value
   CAMLparam5(handle, width, height, spp, max_bounces);
   CAMLxparam3(gpus, image, update_progress);
   CAMLlocal1(exn);
-  ptx_scene* s = Scene_val(handle);
-  if (!s) caml_invalid_argument("Ptx.render: scene already destroyed");
   const intnat w = Long_val(width), h = Long_val(height);
   if (Caml_ba_array_val(image)->dim[0] != w * h * 3) caml_invalid_argument("Ptx.render: image must hold width * height * 3 floats");
+  ptx_scene* s = ptx_ml_scene_acquire(handle);
+  if (!s) caml_invalid_argument("Ptx.render: scene already destroyed");
   double* out = (double*)Caml_ba_data_val(image); /* Bigarray data lives outside the OCaml heap: stable while the lock is released */
   const int32_t i_spp = (int32_t)Long_val(spp), i_mb = (int32_t)Long_val(max_bounces), i_gpus = (int32_t)Long_val(gpus);
   exn = Val_unit;
@@ -185,6 +212,7 @@ CAMLprim value ptx_ml_render_stub(value handle, value width, value height, value
   caml_release_runtime_system();
   const int32_t rc = ptx_ml_render(s, (int32_t)w, (int32_t)h, i_spp, i_mb, i_gpus, out, ptx_ml_progress, &cb);
   caml_acquire_runtime_system();
+  ptx_ml_scene_release(handle);
   if (cb.raised) caml_raise(exn); /* update_progress raised: the render completed, its exception surfaces here */
   if (rc != 0) caml_failwith(ptx_last_error());
   CAMLreturn(Val_unit);
@@ -231,8 +259,6 @@ static void ptx_ml_on_iteration_copy(void* user, int32_t iteration, double radiu
 CAMLprim value ptx_ml_ppm_render_stub(value handle, value params, value lights, value img_sum, value on_iteration) {
   CAMLparam5(handle, params, lights, img_sum, on_iteration);
   CAMLlocal1(exn);
-  ptx_scene* s = Scene_val(handle);
-  if (!s) caml_invalid_argument("Ptx.ppm_render: scene already destroyed");
   if (floatarray_length(params) != 6) caml_invalid_argument("Ptx.ppm_render: params needs 6 floats");
   const int32_t n_lights = floatarray_length(lights) / 11;
   if (floatarray_length(lights) != 11 * n_lights || n_lights < 1 || n_lights > 64)
@@ -244,11 +270,14 @@ CAMLprim value ptx_ml_ppm_render_stub(value handle, value params, value lights, 
   const intnat w = (intnat)p6[0], h = (intnat)p6[1];
   if (w <= 0 || h <= 0 || Caml_ba_array_val(img_sum)->dim[0] != w * h * 3)
     caml_invalid_argument("Ptx.ppm_render: img_sum must hold width * height * 3 floats");
+  ptx_scene* s = ptx_ml_scene_acquire(handle);
+  if (!s) caml_invalid_argument("Ptx.ppm_render: scene already destroyed");
   exn = Val_unit;
   ptx_ml_ppm_cb cb = {{&on_iteration, &exn, 0}, (double*)Caml_ba_data_val(img_sum), (size_t)(w * h * 3)};
   caml_release_runtime_system();
   const int32_t rc = ptx_ml_ppm_render(s, p6, l11, n_lights, cb.img_sum, ptx_ml_on_iteration_copy, &cb);
   caml_acquire_runtime_system();
+  ptx_ml_scene_release(handle);
   if (cb.cb.raised) caml_raise(exn);
   if (rc != 0) caml_failwith(ptx_last_error());
   CAMLreturn(Val_unit);

@@ -118,3 +118,27 @@ def test_python_integrator_mirror(P, tmp_path):
     assert cli_png.read_bytes() == (tmp_path / "py.png").read_bytes()
     with pytest.raises(ValueError):
         I.Integrator.create(width=8, height=8, image=np.zeros((8, 8, 3), dtype=np.float32), samples_per_pixel=1, max_bounces=1, scene=hs)
+
+
+def test_ptx_render_into_a_reused_and_into_fresh_images(P, oracle):
+    """ptx_render's way back to the host: the second render into the SAME caller image page-locks it and copies straight into it
+    from then on; a caller that hands a fresh image per call keeps the staged copy.  Same framebuffer, bit for bit, on every path
+    (first use, registration, registered, another image taking its place, a smaller image, PTX_HOST_REGISTER=0)."""
+    w, h, spp, depth = 768, 512, 2, 4  # 9.4 MB: above the size below which a plain copy is used
+    d = oracle.desc_shirley(w, h)
+    g = P.Scene(d.ptr, 0, keepalive=d)
+    ref, _ = g.render(w, h, spp, depth)
+    same = np.zeros((h, w, 3))
+    for k in range(4):
+        same[:] = -1.0
+        g.render(w, h, spp, depth, out=same)
+        assert np.array_equal(same.view(np.uint64), ref.view(np.uint64)), f"reused image, call {k}"
+    for k in range(3):
+        fresh = np.full((h, w, 3), -1.0)
+        g.render(w, h, spp, depth, out=fresh)
+        assert np.array_equal(fresh.view(np.uint64), ref.view(np.uint64)), f"fresh image, call {k}"
+    for k in range(3):  # back to the first image: registered anew on its second use
+        g.render(w, h, spp, depth, out=same)
+        assert np.array_equal(same.view(np.uint64), ref.view(np.uint64))
+    g.close()  # releases the registration; the image is ours again
+    same[:] = 0.0
