@@ -237,7 +237,7 @@ def measure_extra_workload(torch, P, H, D, dev, local_dev, name, steps=3, warmup
                "dominant_kernel": {"bounce": "k_bounce", "trace": "k_trace", "shade": "k_shade_pool"}.get(dom, dom),
                "dominant_kernel_ms_one_stream": kms.get(dom), "kernel_ms_one_stream": kms,
                "hbm_frame": {"traffic_per_step": hb, "achieved": hb / (ms * 1e-3) * 1e-9, "unit": "GB/s", "frac": hb / (ms * 1e-3) * 1e-9 / HBM_PEAK_GBS,
-                             "source": tc.get("source")} if hb else None}
+                             "source": tc.get("source"), "calibrated": bool(tc.get("calibrated"))} if hb else None}
         try:
             from oracle import oracle as O
             od = {"shirley": lambda: O.desc_shirley(w, h), "cornell": lambda: O.desc_cornell(w, h, 12.0),
@@ -469,8 +469,10 @@ def main():
         bytes_achieved = b_trace / (trace_ms_step * 1e-3) * 1e-9 if trace_ms_step > 0 else 0.0
         hbm_block = {"traffic": traffic, "achieved": (traffic / avg_launch_s * 1e-9) if (traffic and avg_launch_s > 0) else None,
                      "peak": HBM_PEAK_GBS * world, "unit": "GB/s", "peak_measured_copy": copy_gbs,
-                     "source": tc.get("source", "not profiled"),
-                     "note": "HBM bytes per launch of the dominant kernel from rocprofv3 counters (2 x FETCH_SIZE + WRITE_SIZE), over the live launch duration"}
+                     "source": tc.get("source", "not profiled"), "calibrated": bool(tc.get("calibrated")),
+                     "note": "fabric bytes per launch of the dominant kernel from rocprofv3 counters -- reads by request size (128 n128 + 64 n64 + 32 n32; on gfx950 every "
+                             "request is 128 B and FETCH_SIZE tallies it at 64: profiles/r04_fetch_calibration.json) + WRITE_SIZE -- over the live launch duration; "
+                             "Infinity-Cache hits are requests too"}
         hbm_block["frac"] = (hbm_block["achieved"] / hbm_block["peak"]) if hbm_block["achieved"] else None
         if in_lds:
             # tree + packets are LDS-resident: node / slot reads never reach HBM, the binding pipe is vector issue
@@ -539,8 +541,8 @@ def main():
         if hb:
             roofline["hbm_frame"] = {"bound": "hbm", "traffic_per_step": hb, "achieved": hb / (ms_per_step * 1e-3) * 1e-9, "peak": HBM_PEAK_GBS * world,
                                      "unit": "GB/s", "frac": hb / (ms_per_step * 1e-3) * 1e-9 / (HBM_PEAK_GBS * world), "peak_measured_copy": copy_gbs,
-                                     "by_stage": tc.get("hbm_bytes_per_step_by_stage"), "source": tc.get("source"),
-                                     "note": "sum over the step's kernels of rocprofv3 counter bytes (2 x FETCH_SIZE + WRITE_SIZE) x launches, from the tracked profile"}
+                                     "by_stage": tc.get("hbm_bytes_per_step_by_stage"), "source": tc.get("source"), "calibrated": bool(tc.get("calibrated")),
+                                     "note": "sum over the step's kernels of rocprofv3 counter bytes (sized read requests + WRITE_SIZE) x launches, from the tracked profile"}
         # the host-framebuffer entry point the CLI and the OCaml stub call (one 24 B/pixel device-to-host copy more)
         try:
             import numpy as np

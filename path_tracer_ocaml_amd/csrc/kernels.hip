@@ -1549,6 +1549,12 @@ struct PtChunkFeed {
 #ifndef PT_TAIL_CUT
 #define PT_TAIL_CUT 16 /* 0 = off */
 #endif
+#ifndef PT_TAIL_CUT_GLOBAL
+/* scenes walked from HBM / L2 (k_trace): a step of the walk is a round trip to the L2, so lanes that idle while a chunk's long
+ * rays finish cost more there, and a chunk is cut earlier.  Ganesha-like, per-octant node image: trace 23.7 (cut at 16) ->
+ * 22.8 ms (24, 32); round 3 measured 24 / 32 within noise on the three-load walk. */
+#define PT_TAIL_CUT_GLOBAL 32
+#endif
 #ifndef PT_TRACE_DIV_LOOP
 #define PT_TRACE_DIV_LOOP(LDS_SCENE) (PT_WALK_LOOP != 0 || !(LDS_SCENE))
 #endif
@@ -1734,7 +1740,8 @@ __global__ __launch_bounds__(PT_TRACE_BLOCK_OF(MODE, LDS_SCENE), (LDS_SCENE && M
     /* One ray per lane.  TAIL: see PtTailCtl -- a chunk ends when fewer than PT_TAIL_CUT of its rays are still walking;
      * their states (16 bytes each) go to this wave's list in `susp` and once 64 - PT_TAIL_CUT have gathered the wave walks
      * them as a chunk of their own.  tools/sim_coherence.py: 0.527 -> 0.435 wave steps per ray at 16. */
-    constexpr bool TAIL = PT_TAIL_CUT > 0 && PT_DIAG == 0; /* both walks are threaded (LDS image, HBM / L2); a parked camera ray is recomputed from its index */
+    constexpr int CUT = LDS_SCENE ? PT_TAIL_CUT : PT_TAIL_CUT_GLOBAL;
+    constexpr bool TAIL = CUT > 0 && PT_DIAG == 0; /* both walks are threaded (LDS image, HBM / L2); a parked camera ray is recomputed from its index */
     constexpr bool TAIL_UV = TAIL && MODE == PT_MODE_ARRAY; /* triangle hits carry barycentrics: a second 16 bytes per state */
     constexpr bool TAIL_W = TAIL && !LDS_SCENE;            /* 32-bit node index and slot: a third 16 bytes */
     uint4* my_susp = TAIL ? susp + ((size_t)blockIdx.x * (blockDim.x >> 6) + wave_in_block) * (PT_WAVE * 3) : nullptr;
@@ -1744,7 +1751,7 @@ __global__ __launch_bounds__(PT_TRACE_BLOCK_OF(MODE, LDS_SCENE), (LDS_SCENE && M
       bool resume = false, valid = false;
       uint32_t i = 0;
       uint4 parked = make_uint4(0, 0, 0, 0), parked_uv = make_uint4(0, 0, 0, 0), parked_w = make_uint4(0, 0, 0, 0);
-      if (TAIL && (n_susp > (uint32_t)(PT_WAVE - PT_TAIL_CUT) || (!more && n_susp > 0))) {
+      if (TAIL && (n_susp > (uint32_t)(PT_WAVE - CUT) || (!more && n_susp > 0))) {
         resume = true;
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); /* this wave's own parked states, written below */
         valid = (uint32_t)lane < n_susp;
@@ -1780,7 +1787,7 @@ __global__ __launch_bounds__(PT_TRACE_BLOCK_OF(MODE, LDS_SCENE), (LDS_SCENE && M
       if (COUNT && valid && !resume) c_seg++;
       const unsigned long long diag_n0 = c_nodes;
       PtTailCtl tc;
-      tc.min_active = (TAIL && more) ? PT_TAIL_CUT : 0; /* the last chunks of a wave run to completion */
+      tc.min_active = (TAIL && more) ? CUT : 0; /* the last chunks of a wave run to completion */
       tc.resume = resume && valid;
       tc.node = TAIL_W ? parked_w.x : (parked.y & 0xffffu);
       tc.slot = TAIL_W ? (int)parked_w.y : ((int)(parked.y >> 16) == 0xffff ? -1 : (int)(parked.y >> 16));

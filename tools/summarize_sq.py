@@ -19,7 +19,14 @@ SQ_BUSY_CYCLES counts cycles once per shader engine, 32 of them):
   lds_bank_conflict_share = SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE
   wait_any / wait_inst_any / active_inst_any = SQ_* / SQ_WAVE_CYCLES   parked on s_waitcnt or a barrier / stalled at issue / issuing
   wave_residency  = 4 SQ_WAVE_CYCLES / (SQ_WAVES x cycles)             share of the kernel's duration an average wave is alive
-  hbm_bytes_per_launch = (2 FETCH_SIZE + WRITE_SIZE) KB                the gfx950 x2 correction for wide coalesced reads
+  hbm_bytes_per_launch = read bytes + WRITE_SIZE KB.  Read bytes: 128 n128 + 64 n64 + 32 n32 from the sized request counters
+                    (TCC_EA0_RDREQ_{128B,64B,32B}) when the rdreq pass exists -- `"calibrated": true` -- else 2 FETCH_SIZE KB.
+                    profiles/r04_fetch_calibration.json (tools/fetch_calib): on gfx950 every read request of every access shape
+                    tried -- streams, isolated gathers of 16 ... 80-byte records, pooled gathers -- is a 128-byte one, FETCH_SIZE
+                    tallies it at 64 B (its 128-B term, TCC_BUBBLE, reads 0), so 2 x FETCH_SIZE is the fabric read traffic
+                    EXACTLY, not a ceiling; what differs per shape is the over-fetch (a 32-byte record gathered alone costs a line).
+                    These are requests of the L2 to the fabric: Infinity-Cache hits are included (MI355X_MICROARCH.md).
+  l2_read_hit_rate = TCC_HIT / TCC_REQ of the kernel (l2 pass)
 """
 import collections, csv, glob, json, os, shutil, sys
 
@@ -40,7 +47,7 @@ def short(name):
 
 
 passes = {}
-for sub in ("sq_a", "sq_b", "sq_c", "pmc_fetch", "pmc_write"):
+for sub in ("sq_a", "sq_b", "sq_c", "pmc_fetch", "pmc_write", "pmc_rdreq", "pmc_l2"):
     f = newest(os.path.join(src, sub, "*", "*counter_collection.csv"))
     if not f:
         continue
@@ -114,7 +121,23 @@ for k in kernels:
     if f is not None and w is not None and nf and nw:
         e["hbm_fetch_bytes_per_launch_x2_corrected"] = 2.0 * f * 1024.0 / nf
         e["hbm_write_bytes_per_launch"] = w * 1024.0 / nw
-        e["hbm_bytes_per_launch"] = e["hbm_fetch_bytes_per_launch_x2_corrected"] + e["hbm_write_bytes_per_launch"]
+        read_bytes = e["hbm_fetch_bytes_per_launch_x2_corrected"]
+        n128, c128 = val("pmc_rdreq", k, "TCC_EA0_RDREQ_128B_sum")
+        n64, c64 = val("pmc_rdreq", k, "TCC_EA0_RDREQ_64B_sum")
+        n32, c32 = val("pmc_rdreq", k, "TCC_EA0_RDREQ_32B_sum")
+        nall, call = val("pmc_rdreq", k, "TCC_EA0_RDREQ_sum")
+        if n128 is not None and c128:
+            sized = (128.0 * n128 + 64.0 * (n64 or 0.0) + 32.0 * (n32 or 0.0)) / c128
+            e["hbm_read_bytes_per_launch_sized_requests"] = sized
+            e["read_requests_per_launch"] = {"all": (nall or 0.0) / max(call, 1), "128B": n128 / c128, "64B": (n64 or 0.0) / max(c64, 1), "32B": (n32 or 0.0) / max(c32, 1)}
+            e["hbm_calibrated"] = True
+            read_bytes = sized
+        e["hbm_bytes_per_launch"] = read_bytes + e["hbm_write_bytes_per_launch"]
+    req, creq = val("pmc_l2", k, "TCC_REQ_sum")
+    hit, _ = val("pmc_l2", k, "TCC_HIT_sum")
+    if req:
+        e["l2_hit_rate"] = (hit or 0.0) / req
+        e["l2_requests_per_launch"] = req / max(creq, 1)
     if k in dur:
         e["one_stream"] = dur[k]
         if "hbm_bytes_per_launch" in e:
@@ -152,7 +175,7 @@ ri_path = os.path.join(prof, "roofline_inputs.json")
 ri = json.load(open(ri_path)) if os.path.exists(ri_path) else {}
 if tr:
     nl = sum(e["launches"] for e in tr.values())
-    entry = {"source": f"profiles/{tag}_sq.json",
+    entry = {"source": f"profiles/{tag}_sq.json", "calibrated": all(e.get("hbm_calibrated", False) for e in tr.values()),
              "trace_hbm_bytes_per_launch": sum(e.get("hbm_bytes_per_launch", 0.0) * e["launches"] for e in tr.values()) / nl,
              "trace_avg_launch_us_one_stream": sum(e["one_stream"]["avg_us"] * e["one_stream"]["calls"] for e in tr.values() if "one_stream" in e)
                                                / max(sum(e["one_stream"]["calls"] for e in tr.values() if "one_stream" in e), 1)}
