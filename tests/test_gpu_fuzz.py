@@ -118,10 +118,14 @@ def test_mixed_soup_array_leaf_lds(P, oracle, seed, scale):
     assert g_scene.intersect_rays(o, dr)[2]["filter_undecided"] > 0
 
 
+@pytest.mark.parametrize("oct_image", ["1", "0"])
 @pytest.mark.parametrize("seed,scale", [(30, 1.0), (31, 2.0 ** 17), (32, 2.0 ** -9)])
-def test_large_soup_walked_from_hbm(P, oracle, seed, scale):
-    """More nodes than LDS holds: the threaded walk over the 32-byte binary32 image in HBM / L2 (test_box, G32 branch)."""
+def test_large_soup_walked_from_hbm(P, oracle, seed, scale, oct_image, monkeypatch):
+    """More nodes than LDS holds: the threaded walk from HBM / L2 over the per-octant 32-byte node image (two loads per visit,
+    PtThreadOctTag; the default) and over the shared image + skip table it replaces where a leaf does not fit its packed link
+    (PTX_OCT_IMAGE=0) -- test_box, G32 branch.  Same hits, t and counters as the oracle on both."""
     from path_tracer_ocaml_amd import abi
+    monkeypatch.setenv("PTX_OCT_IMAGE", oct_image)  # read when the scene handle is created
     rng = np.random.default_rng(seed)
     centre = rng.uniform(-1.0, 1.0, 3) * scale * 5.0
     d, keep = make_desc(abi, spheres=sphere_soup(rng, 5000, scale, centre, 5.0), tris=triangle_soup(rng, 5000, scale, centre, 3.0),
