@@ -1,0 +1,24 @@
+#!/bin/bash
+# usage (on an MI355X box): tools/round_record.sh <tag>      e.g. r04_final
+# The end-of-round record: full GPU suite log, smoke, the driver's bench command (with its `workloads` block), every workload as its
+# own bench line, the share timings -> gpurun_out/<tag>_*  (copy what should be judged into profiles/).
+tag=${1:-r04_final}
+mkdir -p gpurun_out
+python -m pytest tests -m gpu -x -q > gpurun_out/${tag}_pytest_gpu.log 2>&1; echo "pytest exit $?"; tail -2 gpurun_out/${tag}_pytest_gpu.log
+python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
+python bench.py > gpurun_out/${tag}_bench_n1.json 2> gpurun_out/${tag}_bench_n1.err; echo "bench exit $?"
+python - "$tag" <<'PY'
+import json, sys
+d=json.loads(open('gpurun_out/%s_bench_n1.json' % sys.argv[1]).read().strip().splitlines()[-1])
+r=d['roofline']
+print('headline', round(d['value'],1), 'Msamples/s', round(d['ms_per_step'],2), 'ms; roofline', r['kernel'], r['bound'], 'frac', round(r['frac'],3),
+      'incl. est. shade', round((r.get('incl_estimated_shade') or {}).get('frac', 0),3), 'frame valu', round(r['frame']['frac'],3),
+      'hbm_frame', round(r['hbm_frame']['frac'],3), 'calibrated', r['hbm_frame'].get('calibrated'), 'cpu', d['cpu_baseline']['value'],
+      'parity', d['parity']['rel_linf_vs_cpu_ref'], 'host', d['host_api']['ptx_render_ms'])
+for k, v in d.get('workloads', {}).items():
+    print(' ', k, {a: (round(b, 2) if isinstance(b, float) else b) for a, b in v.items() if a in ('ms_per_step', 'value', 'dominant_kernel', 'dominant_kernel_ms_one_stream', 'error')},
+          'parity', (v.get('parity') or {}).get('rel_linf_vs_cpu_ref'), 'hbm_frame', round(((v.get('hbm_frame') or {}).get('frac') or 0), 3))
+PY
+bash tools/bench_all.sh
+python tools/band_share_timing.py ${tag%_final} 2>/dev/null | tail -8
+python tools/share_step_rate.py 8 60 2>/dev/null | tail -2
