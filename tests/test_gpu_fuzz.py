@@ -241,3 +241,48 @@ def test_random_scene_whole_paths(P, oracle, seed, leaf_kind, cutoff):
     for k in ("segments", "nodes_tested", "prims_tested"):
         assert st[k] == ct[k], k
     assert ct["segments"] > 2 * n
+
+
+@pytest.mark.parametrize("n_floor", [2, 4, 7])
+def test_many_pretested_floor_triangles_with_a_tree_walked_from_hbm(P, oracle, n_floor):
+    """Triangles tested before the tree (ganesha's Floor, main.ml:247-256): the walk from HBM / L2 keeps the first four in LDS and
+    reads further ones from global memory.  2, 4 and 7 of them over a soup too large for LDS: hit primitive (floor slots included),
+    t, and the floor / node / slot counters equal the oracle's; whole paths are traced per sample bit for bit."""
+    from path_tracer_ocaml_amd import abi
+    rng = np.random.default_rng(40 + n_floor)
+    centre = np.array([0.0, 0.0, -30.0])
+    d, keep = make_desc(abi, tris=triangle_soup(rng, 9000, 1.0, centre, 3.0), leaf_kind=1, cutoff=4)
+    # n_floor large triangles fanned out below the soup (camera space: y down = lower values)
+    fv = []
+    for k in range(n_floor):
+        a0, a1 = 2 * np.pi * k / n_floor, 2 * np.pi * (k + 1) / n_floor
+        fv += [centre[0], centre[1] - 6.0, centre[2],
+               centre[0] + 40 * np.cos(a0), centre[1] - 6.0 - 0.1 * k, centre[2] + 40 * np.sin(a0),
+               centre[0] + 40 * np.cos(a1), centre[1] - 6.0 + 0.05 * k, centre[2] + 40 * np.sin(a1)]
+    fv = np.array(fv, dtype=np.float64)
+    fuv = np.tile(np.array([0.0, 0.0, 1.0, 0.0, 1.0, 1.0]), n_floor)
+    fm = np.zeros(n_floor, dtype=np.int32)
+    keep += [fv, fuv, fm]
+    d.n_floor_triangles = n_floor
+    d.floor_vertices = fv.ctypes.data_as(abi.c_double_p)
+    d.floor_uv = fuv.ctypes.data_as(abi.c_double_p)
+    d.floor_material = fm.ctypes.data_as(abi.c_int32_p)
+    o_scene, g_scene = both(P, oracle, d, keep)
+    assert not g_scene.stats()["traversal_in_lds"]
+    n = 30000
+    o = centre + rng.uniform(-2.0, 2.0, (n, 3)) + np.array([0.0, 3.0, 0.0])
+    dr = rng.normal(size=(n, 3))
+    dr[: n // 2, 1] = -np.abs(dr[: n // 2, 1]) - 0.3  # half of them aimed at the floor fan
+    dr /= np.linalg.norm(dr, axis=1, keepdims=True)
+    t_c, p_c, ct = o_scene.intersect_rays(o, dr)
+    t_g, p_g, st = g_scene.intersect_rays(o, dr)
+    assert np.array_equal(p_g, p_c) and np.array_equal(bits(t_g), bits(t_c))
+    for k in ("nodes_tested", "prims_tested", "floor_tested"):
+        assert st[k] == ct[k], k
+    n_slots = g_scene.stats()["leaf_slots"]
+    assert st["floor_tested"] >= n and (p_c >= 0).sum() > 1000
+    w, h, spp, depth = 64, 48, 3, 5
+    xs, ys, ps = rng.integers(0, w, 3000), rng.integers(0, h, 3000), rng.integers(0, spp, 3000)
+    g_rgb, _ = g_scene.trace_samples(w, h, spp, depth, xs, ys, ps)
+    o_rgb, _ = o_scene.trace_samples(w, h, spp, depth, xs, ys, ps)
+    assert np.array_equal(bits(g_rgb), bits(o_rgb))
