@@ -547,14 +547,15 @@ def main():
         try:
             import numpy as np
             fb = np.zeros((h, w, 3))  # the caller's image, allocated and touched once like the reference's Bimage
+            scene.pin_image(fb)       # ... and pinned for its lifetime, as the CLI and the OCaml stub do (ptx_image_pin)
             scene.render(w, h, spp, depth, out=fb)
-            scene.render(w, h, spp, depth, out=fb)  # the second render into the same image page-locks it (one-time cost)
             t2 = time.perf_counter()
             for _ in range(3):
                 scene.render(w, h, spp, depth, out=fb)
             host_ms = (time.perf_counter() - t2) * 1e3 / 3
+            scene.unpin_image()
             host_api = {"ptx_render_ms": host_ms, "msamples_per_s": samples / host_ms * 1e-3,
-                        "note": "ptx_render: whole frame on this GPU, post-gamma framebuffer copied into the caller's host image (PCIe inclusive: never `value`)"} if world == 1 else None
+                        "note": "ptx_render: whole frame on this GPU, post-gamma framebuffer copied into the caller's host image, pinned by the caller for its lifetime like the CLI's (ptx_image_pin; PCIe inclusive: never `value`)"} if world == 1 else None
         except Exception as e:
             host_api = {"ptx_render_ms": None, "note": f"unavailable: {e}"}
         out = {

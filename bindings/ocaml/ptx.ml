@@ -143,6 +143,12 @@ external scene_destroy : scene -> unit = "ptx_ml_scene_destroy_stub"
 (* tree depth, nodes, leaves, leaf slots: what main.ml prints after Shape_tree.create (ganesha/bin/main.ml:191-195) *)
 external scene_tree_stats : scene -> int * int * int * int = "ptx_ml_scene_tree_stats_stub"
 
+(* Optional: page-lock the image the renders go into (ptx_image_pin): the frame then comes back with one DMA.  A Bigarray's data
+   is outside the OCaml heap and does not move; the pin must end (image_unpin, scene_destroy) before the image is collected --
+   with_pinned_image below keeps the image reachable for exactly that long. *)
+external image_pin : scene -> (float, Bigarray.float64_elt, Bigarray.c_layout) Bigarray.Array1.t -> unit = "ptx_ml_image_pin_stub"
+external image_unpin : scene -> unit = "ptx_ml_image_unpin_stub"
+
 external render_flat
   :  scene
   -> int (* width *)
@@ -323,6 +329,15 @@ let mesh_bbox (mesh : mesh) =
 (* Integrator.create ... |> Integrator.render ~update_progress, on [gpus] GPUs of this node *)
 let render ?(gpus = 1) scene ~width ~height ~samples_per_pixel ~max_bounces ~image ~update_progress =
   render_flat scene width height samples_per_pixel max_bounces gpus image update_progress
+;;
+
+(* [f ()] with [image] pinned; a host that renders many frames into one Bimage (an animation loop around Render_command's run)
+   wraps the loop in this.  A pin that cannot be had is not an error: the renders then take the staged copy. *)
+let with_pinned_image scene image f =
+  (try image_pin scene image with Failure _ -> ());
+  Fun.protect f ~finally:(fun () ->
+    image_unpin scene;
+    ignore (Sys.opaque_identity image))
 ;;
 
 (* Progressive_photon_map.Make(Scene).go without its prints and its PNG: [img_sum] (W*H*3, the data of a Bimage f64 rgb)

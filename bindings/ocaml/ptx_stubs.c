@@ -172,6 +172,19 @@ CAMLprim value ptx_ml_scene_tree_stats_stub(value handle) {
   CAMLreturn(tuple);
 }
 
+/* external image_pin : scene -> image -> unit = "ptx_ml_image_pin_stub" / external image_unpin : scene -> unit (ptx_image_pin) */
+CAMLprim value ptx_ml_image_pin_stub(value handle, value image) {
+  ptx_scene* s = Scene_val(handle);
+  if (!s) caml_invalid_argument("Ptx.image_pin: scene already destroyed");
+  if (ptx_image_pin(s, (double*)Caml_ba_data_val(image), (int64_t)Caml_ba_array_val(image)->dim[0]) != 0) caml_failwith(ptx_last_error());
+  return Val_unit;
+}
+CAMLprim value ptx_ml_image_unpin_stub(value handle) {
+  ptx_scene* s = Scene_val(handle);
+  if (s) (void)ptx_image_unpin(s);
+  return Val_unit;
+}
+
 /* What a callback trampoline needs: the closure (a GC root registered by the stub that owns this struct) and the first
  * exception a callback raised.  While `raised` is set no further callbacks are made. */
 typedef struct ptx_ml_cb {

@@ -264,6 +264,16 @@ ptx_scene* ptx_scene_replicate(const ptx_scene* scene, int32_t device);
 /* Frees the calling thread's cached GPU-BVH-builder buffers (they otherwise live as long as the thread). */
 void ptx_release_workspaces(void);
 
+/* Optional: page-lock the caller's framebuffer for as long as it will be rendered into.  ptx_render / ptx_render_multi into
+ * exactly this image (rgb_out inside [image, image + n_doubles)) then fill it with ONE DMA instead of copying through a staging
+ * buffer (1080p: ~1.1 ms instead of ~2.8).  The reference's image lives as long as the run (the Bimage of
+ * render_command/src/render_command.ml:64-70), which is the caller this is for.  CONTRACT: the image must stay mapped until
+ * ptx_image_unpin or ptx_scene_destroy -- a DMA into a registration whose pages were unmapped aborts the process -- which is
+ * why the library never pins an image behind the caller's back.  One pinned image per handle (pinning another releases the
+ * first).  Returns 0, or an error code (the caller may ignore it: renders then take the staged copy). */
+int32_t ptx_image_pin(ptx_scene* scene, double* image, int64_t n_doubles);
+int32_t ptx_image_unpin(ptx_scene* scene);
+
 /* Device-resident form, for one rank of a multi-GPU job and for benchmarking with no
  * PCIe traffic in the timed region.  d_raw_out is DEVICE memory holding this rank's
  * rows compactly: ptx_local_rows(params) * width * 3 doubles of raw per-pixel radiance

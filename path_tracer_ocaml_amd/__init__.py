@@ -34,6 +34,7 @@ EXPORTS = (
     "ptx_film_resolve_device", "ptx_trace_samples", "ptx_intersect_rays", "ptx_scene_tree", "ptx_lds_sample",
     "ptx_math_eval", "ptx_ppm_render", "ptx_debug_first_scatter", "ptx_render_multi", "ptx_scene_replicate",
     "ptx_film_resolve_banded_device", "ptx_film_resolve_banded_queue", "ptx_release_workspaces",
+    "ptx_image_pin", "ptx_image_unpin",
 )
 
 PROGRESS_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_int64)
@@ -77,6 +78,8 @@ def lib():
     L.ptx_scene_replicate.restype = C.c_void_p
     L.ptx_scene_replicate.argtypes = [C.c_void_p, C.c_int32]
     L.ptx_release_workspaces.restype = None
+    L.ptx_image_pin.argtypes = [C.c_void_p, dp, C.c_int64]
+    L.ptx_image_unpin.argtypes = [C.c_void_p]
     L.ptx_trace_samples.argtypes = [C.c_void_p, C.POINTER(abi.RenderParams), C.c_int64, ip, ip, ip, dp,
                                     C.POINTER(abi.Stats)]
     L.ptx_intersect_rays.argtypes = [C.c_void_p, C.c_int64, dp, dp, dp, ip, C.POINTER(abi.Stats)]
@@ -183,6 +186,18 @@ class Scene:
         cb = PROGRESS_FN(lambda user, n: progress(n)) if progress else None
         _check(lib().ptx_render(self._h, C.byref(p), _dp(out), C.byref(st), C.cast(cb, C.c_void_p) if cb else None, None))
         return out, stats_dict(st)
+
+    def pin_image(self, image):
+        """ptx_image_pin: page-lock the caller's (H, W, 3) float64 image for as long as renders go into it (one DMA per frame
+        instead of a staged copy).  The image must stay alive until unpin_image() / close()."""
+        if image.dtype != np.float64 or not image.flags["C_CONTIGUOUS"]:
+            raise ValueError("image must be a C-contiguous float64 array")
+        _check(lib().ptx_image_pin(self._h, _dp(image), image.size))
+        self._pinned_image = image  # keeps it mapped while the registration exists
+
+    def unpin_image(self):
+        _check(lib().ptx_image_unpin(self._h))
+        self._pinned_image = None
 
     def render_raw_device(self, params, d_raw_ptr, stream=None):
         """ptx_render_raw_device: raw per-pixel sums for this rank's rows into DEVICE memory."""

@@ -169,7 +169,11 @@ int main(int argc, char** argv) {
   prog.total = (long long)a.width * a.height;
   prog.t0 = prog.last = now_ms();
   const double t0 = now_ms();
+  /* the image lives until the PNG is written, like the reference's Bimage (render_command.ml:64-70): pin it, so the frame comes
+   * back with one DMA (optional: a failure only means the staged copy) */
+  (void)ptx_image_pin(scene, rgb.data(), (int64_t)rgb.size());
   const int rc = ptx_render(scene, &p, rgb.data(), &st, a.no_progress ? nullptr : on_progress, &prog);
+  (void)ptx_image_unpin(scene);
   const double elapsed = now_ms() - t0;
   if (rc != 0) {
     std::fprintf(stderr, "ptx_render: %s\n", ptx_last_error());

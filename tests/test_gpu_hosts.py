@@ -120,25 +120,36 @@ def test_python_integrator_mirror(P, tmp_path):
         I.Integrator.create(width=8, height=8, image=np.zeros((8, 8, 3), dtype=np.float32), samples_per_pixel=1, max_bounces=1, scene=hs)
 
 
-def test_ptx_render_into_a_reused_and_into_fresh_images(P, oracle):
-    """ptx_render's way back to the host: the second render into the SAME caller image page-locks it and copies straight into it
-    from then on; a caller that hands a fresh image per call keeps the staged copy.  Same framebuffer, bit for bit, on every path
-    (first use, registration, registered, another image taking its place, a smaller image, PTX_HOST_REGISTER=0)."""
+def test_ptx_render_into_pinned_and_unpinned_images(P, oracle):
+    """ptx_render's way back to the host: a staged copy into any image, one DMA into an image the caller has pinned
+    (ptx_image_pin: the caller promises to keep it mapped until ptx_image_unpin / ptx_scene_destroy -- the library never pins
+    behind the caller's back, a DMA into a stale registration aborts the process).  Same framebuffer, bit for bit, on every path:
+    unpinned, pinned, a sub-range of the pinned image, another image while one is pinned, after unpin, after re-pinning another."""
     w, h, spp, depth = 768, 512, 2, 4  # 9.4 MB: above the size below which a plain copy is used
     d = oracle.desc_shirley(w, h)
     g = P.Scene(d.ptr, 0, keepalive=d)
     ref, _ = g.render(w, h, spp, depth)
-    same = np.zeros((h, w, 3))
-    for k in range(4):
-        same[:] = -1.0
-        g.render(w, h, spp, depth, out=same)
-        assert np.array_equal(same.view(np.uint64), ref.view(np.uint64)), f"reused image, call {k}"
-    for k in range(3):
-        fresh = np.full((h, w, 3), -1.0)
-        g.render(w, h, spp, depth, out=fresh)
-        assert np.array_equal(fresh.view(np.uint64), ref.view(np.uint64)), f"fresh image, call {k}"
-    for k in range(3):  # back to the first image: registered anew on its second use
-        g.render(w, h, spp, depth, out=same)
-        assert np.array_equal(same.view(np.uint64), ref.view(np.uint64))
-    g.close()  # releases the registration; the image is ours again
-    same[:] = 0.0
+    img = np.full((h, w, 3), -1.0)
+    g.render(w, h, spp, depth, out=img)
+    assert np.array_equal(img.view(np.uint64), ref.view(np.uint64))
+    big = np.full((2, h, w, 3), -1.0)
+    g.pin_image(big)
+    for k in range(2):  # both halves of the pinned allocation
+        g.render(w, h, spp, depth, out=big[k])
+        assert np.array_equal(big[k].view(np.uint64), ref.view(np.uint64)), f"pinned image, half {k}"
+    other = np.full((h, w, 3), -1.0)
+    g.render(w, h, spp, depth, out=other)  # not the pinned one: staged
+    assert np.array_equal(other.view(np.uint64), ref.view(np.uint64))
+    g.pin_image(other)  # replaces the first registration
+    g.render(w, h, spp, depth, out=other)
+    assert np.array_equal(other.view(np.uint64), ref.view(np.uint64))
+    big[:] = -3.0
+    g.render(w, h, spp, depth, out=big[0])  # no longer pinned: staged again
+    assert np.array_equal(big[0].view(np.uint64), ref.view(np.uint64))
+    g.unpin_image()
+    g.unpin_image()  # idempotent
+    g.render(w, h, spp, depth, out=other)
+    assert np.array_equal(other.view(np.uint64), ref.view(np.uint64))
+    g.pin_image(img)
+    g.close()  # destroy releases the registration
+    img[:] = 0.0
