@@ -3041,7 +3041,7 @@ __global__ __launch_bounds__(PT_BOUNCE_THREADS, PT_BOUNCE_WAVES) void k_bounce(P
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #endif
   }
-  if (COUNT) {
+  if (COUNT && !(PT_DIAG != 0 && PRIMARY)) { /* (diagnostic builds measure the queued rays' launches only) */
     c_nodes = pt_wave_sum(c_nodes);
     c_prims = pt_wave_sum(c_prims);
     c_floor = pt_wave_sum(c_floor);
