@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define PTX_ABI_VERSION 4
+#define PTX_ABI_VERSION 5
 
 /* ---- materials: Material.t, path_tracer/src/material.ml:3-14 ---- */
 #define PTX_MAT_LAMBERTIAN 0 /* Lambertian of Texture.t */
