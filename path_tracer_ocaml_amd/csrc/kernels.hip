@@ -502,9 +502,10 @@ struct PtTraverser {
   uint32_t walking; /* 0 / 1: an integer, so that "wants a node step" is ONE unsigned comparison (walking > leaf_n) */
   int leaf_first, leaf_n;
   __device__ __forceinline__ bool wants_node() const { return walking > (uint32_t)leaf_n; }
-  /* the same as a wave mask, straight from the comparison (a ballot of a boolean that is also branched on costs two more
-   * vector instructions per turn, and the walk is bound by vector issue); 34 = unsigned greater than, 38 = signed greater than */
-  __device__ __forceinline__ unsigned long long wants_node_mask() const { return __builtin_amdgcn_uicmp(walking, (uint32_t)leaf_n, 34); }
+  /* the same as a wave mask, straight from the comparison: the ballot builtin of the very expression the branch tests lets the
+   * compiler use ONE v_cmp for both (HIP's __ballot of a boolean that is also branched on costs two more vector instructions
+   * per turn; __builtin_amdgcn_uicmp a second compare); 38 = signed greater than, 33 = not equal */
+  __device__ __forceinline__ unsigned long long wants_node_mask() const { return __builtin_amdgcn_ballot_w64(walking > (uint32_t)leaf_n); }
   __device__ __forceinline__ unsigned long long holds_leaf_mask() const { return __builtin_amdgcn_sicmp(leaf_n, 0, 38); }
   __device__ __forceinline__ unsigned long long walking_mask() const { return __builtin_amdgcn_uicmp(walking, 0u, 33); }
   __device__ __forceinline__ bool idle() const { return !walking && leaf_n == 0; }
@@ -1130,7 +1131,7 @@ __device__ __forceinline__ PtTraceResult pt_trace_ray(const PtSceneDev& sc, cons
         tr.node_step(sv, stack, c_nodes, c_prims);
         if (__ballot(tr.leaf_n > 0) != 0) leaf_waiting = true;
         if (!tr.wants_node()) break;
-        if (leaf_waiting && (int)__popcll(__ballot(1)) < PT_WALK_MIN) break;
+        if (leaf_waiting && pt_popc_mask(__builtin_amdgcn_ballot_w64(true)) < PT_WALK_MIN) break;
       }
      }
     } else {
@@ -2878,6 +2879,9 @@ __global__ __launch_bounds__(PT_POOL_THREADS, PT_SHADE_WAVES) void k_shade_pool(
 #ifndef PT_BOUNCE_MIN_CHUNKS
 #define PT_BOUNCE_MIN_CHUNKS 2 /* chunks per wave below which fewer workgroups take part (k_shade_pool: 16 -- there a chunk is a few microseconds) */
 #endif
+#ifndef PT_DIAG_FLOOR
+#define PT_DIAG_FLOOR 0 /* diagnostic builds only: 1 = k_bounce returns once the scene image is in LDS, 2 = at once (the launch floor) */
+#endif
 #ifndef PT_BOUNCE_FENCE_WG
 #define PT_BOUNCE_FENCE_WG 0 /* 1: workgroup-scope fences (s_waitcnt vmcnt(0)) around the wave's own hit / parked records instead of wavefront scope */
 #endif
@@ -2897,9 +2901,15 @@ __global__ __launch_bounds__(PT_BOUNCE_THREADS, PT_BOUNCE_WAVES) void k_bounce(P
   uint32_t n_wg = total_chunks / (uint32_t)(PT_BOUNCE_MIN_CHUNKS * nw);
   n_wg = n_wg < 1u ? 1u : (n_wg > gridDim.x ? gridDim.x : n_wg);
   if (blockIdx.x >= n_wg) return; /* workgroup-uniform */
+#if PT_DIAG_FLOOR == 2
+  if (gridDim.x > 0) return; /* diagnostic build (tools/README.md): what a launch costs before it does anything */
+#endif
   if (threadIdx.x == 0) { lds_chunk_ctr = 0u; lds_done = 0u; }
   if (threadIdx.x < PT_POOL_BINS) lds_out[threadIdx.x] = (PT_POOL_NO_BLOCK << 12) | (uint32_t)PT_POOL_BLOCK; /* "full": the first push brings a block */
   const PtSceneView sv = pt_scene_view<MODE, true, StackT>(sc, lds_raw, stack_depth); /* ends with the workgroup's only barrier */
+#if PT_DIAG_FLOOR == 1
+  if (gridDim.x > 0) return; /* diagnostic build: launch + the scene image in LDS, nothing else */
+#endif
   uint2 (*pool)[128] = (uint2 (*)[128])(lds_raw + pool_off) + (size_t)wave * PT_N_SHADE_CAT;
   uint32_t cnt[PT_N_SHADE_CAT];
 #pragma unroll
