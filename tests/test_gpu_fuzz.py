@@ -9,6 +9,7 @@ few binary32 ulps (where entry and exit distances coincide and the filter must g
 the work counters (nodes tested, slots tested) equal the oracle's bit for bit, and the undecided branch provably ran
 (ptx_stats.filter_undecided > 0 where grazing rays are present).  Seeds are fixed."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -82,9 +83,11 @@ def leaf_boxes(g_scene):
 
 
 SCALES = [2.0 ** -20, 2.0 ** -7, 1.0, 2.0 ** 9, 2.0 ** 21]
+# a soak run (tools/round_record.sh) adds PTX_FUZZ_SEEDS fresh seeds to the two LDS-resident soups below
+SOAK = [(100 + k, SCALES[k % len(SCALES)]) for k in range(int(os.environ.get("PTX_FUZZ_SEEDS", "0")))]
 
 
-@pytest.mark.parametrize("seed,scale", [(s, sc) for s, sc in enumerate(SCALES)] + [(7, 1.0), (8, 2.0 ** 21), (9, 2.0 ** -20)])
+@pytest.mark.parametrize("seed,scale", [(s, sc) for s, sc in enumerate(SCALES)] + [(7, 1.0), (8, 2.0 ** 21), (9, 2.0 ** -20)] + SOAK)
 def test_sphere_soup_simd_leaf(P, oracle, seed, scale):
     from path_tracer_ocaml_amd import abi
     rng = np.random.default_rng(1000 + seed)
@@ -100,7 +103,7 @@ def test_sphere_soup_simd_leaf(P, oracle, seed, scale):
     assert st["filter_fallback_steps"] > 0
 
 
-@pytest.mark.parametrize("seed,scale", [(20, 2.0 ** -12), (21, 1.0), (22, 2.0 ** 14), (23, 2.0 ** 21)])
+@pytest.mark.parametrize("seed,scale", [(20, 2.0 ** -12), (21, 1.0), (22, 2.0 ** 14), (23, 2.0 ** 21)] + SOAK)
 def test_mixed_soup_array_leaf_lds(P, oracle, seed, scale):
     """Array_leaf with spheres AND triangles (cornell's mixed leaf, cornell-box/bin/main.ml:93-155), LDS-resident."""
     from path_tracer_ocaml_amd import abi
