@@ -24,6 +24,6 @@ python tools/band_share_timing.py ${tag%_final} 2>/dev/null | tail -8
 python tools/share_step_rate.py 8 60 2>/dev/null | tail -2
 # soak: fresh seeds beyond the suite's fixed ones (random render configurations bit for bit against the oracle; random soups of the fuzz module)
 if [ "${SOAK:-1}" != "0" ]; then
-  PTX_TEST_SEEDS=${SOAK_RENDER_SEEDS:-300} PTX_FUZZ_SEEDS=${SOAK_FUZZ_SEEDS:-40} timeout -k 10 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_fuzz.py -m gpu -q \
+  PTX_TEST_SEEDS=${SOAK_RENDER_SEEDS:-5000} PTX_FUZZ_SEEDS=${SOAK_FUZZ_SEEDS:-500} timeout -k 10 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_fuzz.py -m gpu -q \
     -k "random_configs or soup" > gpurun_out/${tag}_soak.log 2>&1; echo "soak exit $?"; tail -1 gpurun_out/${tag}_soak.log
 fi
