@@ -1990,6 +1990,9 @@ __host__ __device__ __forceinline__ Quat pt_shader_rotation(V3 normal) {
   }
   return q;
 }
+/* Triangle.Hit.to_hit's geometric normal (triangle.ml:43-64) */
+#define PT_TRI_FRAME_DOUBLES 12
+__host__ __device__ __forceinline__ V3 pt_tri_normal(V3 a, V3 b, V3 c) { return v3_normalize(v3_cross(v3_sub(b, a), v3_sub(c, a))); }
 __device__ __forceinline__ Quat pt_quat_conj(Quat q) {
   Quat c;
   c.r = q.r;
@@ -2110,7 +2113,10 @@ __device__ __forceinline__ PtSurface pt_surface_hit(const PtSceneDev& sc, V3 o, 
     /* Triangle.Hit.to_hit (triangle.ml:43-64) */
     const double* tvx = sc.tri + (size_t)slot * 10;
     const V3 a = pt_load_v3(tvx), b = pt_load_v3(tvx + 3), c = pt_load_v3(tvx + 6);
-    const V3 g_normal = v3_normalize(v3_cross(v3_sub(b, a), v3_sub(c, a)));
+    const bool framed = sc.tri_frame != nullptr; /* (wave-uniform) */
+    V3 g_normal;
+    if (framed) g_normal = pt_load_v3(sc.tri_frame + (size_t)slot * PT_TRI_FRAME_DOUBLES);
+    else g_normal = pt_tri_normal(a, b, c);
     const double u = bu, v = bv;
     const double w = 1.0 - u - v;
     sf.point = v3_add(v3_add(v3_scale(a, w), v3_scale(b, u)), v3_scale(c, v));
@@ -2119,6 +2125,14 @@ __device__ __forceinline__ PtSurface pt_surface_hit(const PtSceneDev& sc, V3 o, 
     sf.tv = (uv[1] * w) + (uv[3] * u) + (uv[5] * v);
     sf.hit_front = v3_dot(d, g_normal) < 0.0;
     sf.normal = sf.hit_front ? g_normal : v3_neg(g_normal);
+    if (framed) { /* Shader_space.create of that normal: one of the slot's two precomputed rotations (PtSceneDev.tri_frame) */
+      const double* r = sc.tri_frame + (size_t)slot * PT_TRI_FRAME_DOUBLES + (sf.hit_front ? 4 : 8);
+      const double2 r0 = ((const double2*)r)[0], r1 = ((const double2*)r)[1];
+      sf.rot.r = r0.x;
+      sf.rot.v = v3(r0.y, r1.x, r1.y);
+      sf.omega_i = pt_quat_transform(sf.rot, v3_neg(d));
+      return sf;
+    }
   }
   sf.rot = pt_shader_rotation(sf.normal);
   sf.omega_i = pt_quat_transform(sf.rot, v3_neg(d)); /* Shader_space.omega_i */

@@ -87,6 +87,11 @@ struct PtSceneDev {
   const double* sph;   /* n_slots x 4 (valid where slot_kind != TRIANGLE) */
   const double* tri;   /* n_slots x 10 (valid where slot_kind == TRIANGLE); NULL if no triangles */
   const double* tri_uv;/* n_slots x 6 */
+  /* Small scenes with triangles: what Triangle.Hit.to_hit + Shader_space.create derive from the triangle ALONE, per slot, 12 doubles:
+   * {g_normal xyz, -, rotation of +g_normal (r, x, y, z), rotation of -g_normal}.  Computed once on the host with the functions
+   * the shade step itself uses (pt_surface_hit), so a load replaces ~130 vector instructions per triangle hit with the same
+   * bits.  NULL: the shade step computes them (large meshes: the table would be one more gathered line per segment). */
+  const double* tri_frame;
   const uint8_t* slot_kind;
   const uint8_t* slot_cat;  /* shading category of the slot's material, PT_CAT_* (wave-coherent shading) */
   const int32_t* slot_material;
