@@ -421,6 +421,8 @@ struct PtSceneView {
   const double* sph;
   const double* tri;
   const uint8_t* kind;
+  const uint8_t* cat; /* the slots' shading categories: the LDS copy on LDS-resident scenes (k_bounce files a finished ray by it right
+                         after the walk: from global memory that one byte was a ~1 us round trip in every chunk's chain) */
   /* scenes walked from HBM / L2: the first n_floor_lds floor triangles (ganesha's Floor, tested before the tree for EVERY ray,
    * main.ml:247-256) as 10-double records in LDS.  Read from global memory their 2 x 5 loads per ray were a fifth of the
    * walk's vector-memory instructions -- all lanes at the same address, but the texture-address unit that binds this kernel
@@ -467,7 +469,8 @@ __device__ __forceinline__ uint32_t pt_stack_pop(const PtThreadOctTag*, int) { r
 #endif
 /* PT_DIAG (diagnostic builds only, tools/diag_utilisation.sh): re-purposes the COUNT counters of SECONDARY launches
  * to measure lane utilisation per traversal phase: nodes = useful lane steps, floor = lane slots the wave spent.
- * 1: node walk   2: node walk if only the per-chunk tail were lost   3: packet scan   4: packet heavy part */
+ * 1: node walk   2: node walk if only the per-chunk tail were lost   3: packet scan   4: packet heavy part
+ * 5 / 6 (k_bounce only, tools/diag_phases.py): a wave's life in 100 MHz ticks per phase -- walk / shade steps / rest, or walk / its leaf phases */
 #ifndef PT_DIAG
 #define PT_DIAG 0
 #endif
@@ -1146,6 +1149,13 @@ __device__ __forceinline__ PtTraceResult pt_trace_ray(const PtSceneDev& sc, cons
       tr.node_step(sv, stack, c_nodes, c_prims);
     }
     }
+    if (COUNT && PT_DIAG == 6 && !ORIGIN_ZERO) { /* (diagnostic build: ticks the wave spends in the leaf phase, into c_prims; lane 0's copy is kept) */
+      __builtin_amdgcn_sched_barrier(0);
+      const unsigned long long t0_ = __builtin_readcyclecounter();
+      if (tr.leaf_n > 0) tr.packet(sv, c_nodes, c_floor);
+      __builtin_amdgcn_sched_barrier(0);
+      c_prims += __builtin_readcyclecounter() - t0_;
+    } else
     if (tr.leaf_n > 0) tr.packet(sv, c_nodes, c_floor);
     /* nobody holds a leaf here: a safe place to stop.  The ballot sees the rays that are still walking (finished
      * lanes have left the loop), and every one of them sees the same count. */
@@ -1384,6 +1394,7 @@ __device__ __forceinline__ PtSceneView pt_scene_view(const PtSceneDev& sc, unsig
   sv.sph = sc.sph;
   sv.tri = sc.tri;
   sv.kind = sc.slot_kind;
+  sv.cat = sc.slot_cat;
 #if PT_LEAF_PREFETCH
   if (!LDS_SCENE && sc.all_triangles) sv.kind = nullptr; /* PtTraverser::packet: the pipelined triangle loop */
 #endif
@@ -1397,6 +1408,8 @@ __device__ __forceinline__ PtSceneView pt_scene_view(const PtSceneDev& sc, unsig
     double* l_tri = (double*)(lds_raw + off);
     if (MODE == PT_MODE_ARRAY && sc.has_triangles) off += (size_t)total_slots * 10 * sizeof(double);
     uint8_t* l_kind = (uint8_t*)(lds_raw + off);
+    if (MODE == PT_MODE_ARRAY) off += ((size_t)total_slots + 15) & ~(size_t)15;
+    uint8_t* l_cat = (uint8_t*)(lds_raw + off);
     /* nodes: the binary32 filter image (PT_SWZ_NODE_BYTES each); links become byte offsets into it -- with PT_SWZ_SIGNSEL,
      * absolute LDS addresses (layout 3 above) */
 #if PT_SWZ_SIGNSEL
@@ -1450,12 +1463,14 @@ __device__ __forceinline__ PtSceneView pt_scene_view(const PtSceneDev& sc, unsig
       }
       for (int k = threadIdx.x; k < total_slots; k += blockDim.x) l_kind[k] = sc.slot_kind[k];
     }
+    for (int k = threadIdx.x; k < total_slots; k += blockDim.x) l_cat[k] = sc.slot_cat[k];
     __syncthreads();
     sv.swz_nodes = l_nodes;
     sv.swz_root = nbase;
     sv.sph = l_sph;
     sv.tri = l_tri;
     sv.kind = l_kind;
+    sv.cat = l_cat;
   }
   return sv;
 }
@@ -2893,6 +2908,9 @@ __global__ __launch_bounds__(PT_POOL_THREADS, PT_SHADE_WAVES) void k_shade_pool(
 #ifndef PT_BOUNCE_MIN_CHUNKS
 #define PT_BOUNCE_MIN_CHUNKS 2 /* chunks per wave below which fewer workgroups take part (k_shade_pool: 16 -- there a chunk is a few microseconds) */
 #endif
+#ifndef PT_LDS_CAT
+#define PT_LDS_CAT 1 /* k_bounce reads a finished ray's shading category from the LDS copy (PtSceneView.cat); 0: from global memory */
+#endif
 #ifndef PT_DIAG_FLOOR
 #define PT_DIAG_FLOOR 0 /* diagnostic builds only: 1 = k_bounce returns once the scene image is in LDS, 2 = at once (the launch floor) */
 #endif
@@ -2934,7 +2952,16 @@ __global__ __launch_bounds__(PT_BOUNCE_THREADS, PT_BOUNCE_WAVES) void k_bounce(P
   uint32_t n_susp = 0; /* wave-uniform */
   bool more = true;    /* wave-uniform: the workgroup's share of the queue is not exhausted */
   unsigned long long c_nodes = 0, c_prims = 0, c_floor = 0, c_seg = 0, c_filter[2] = {0, 0}; /* COUNT: as in k_trace */
+  /* PT_DIAG == 5 (tools/diag_phases.py; counting renders of diagnostic builds, queued rays' launches): where a wave's life goes,
+   * in ticks of the 100 MHz clock summed over waves -- nodes = walks, prims = shade steps (with their pushes), floor = everything
+   * else in the loop (chunk hand-out, ray loads, filing, parking), segments = the whole loop; undecided / fallback_steps = the
+   * number of shade steps / walks */
+  constexpr bool DIAG_T = COUNT && (PT_DIAG == 5 || PT_DIAG == 6) && !PRIMARY; /* 6: prims = the walks' leaf phases instead of the shade steps */
+  unsigned long long tm_last = DIAG_T ? __builtin_readcyclecounter() : 0ull;
+  const unsigned long long tm_begin = tm_last;
+#define PT_TM5(var) do { if (DIAG_T) { __builtin_amdgcn_sched_barrier(0); const unsigned long long now_ = __builtin_readcyclecounter(); (var) += now_ - tm_last; tm_last = now_; __builtin_amdgcn_sched_barrier(0); } } while (0)
   for (;;) {
+    PT_TM5(c_floor);
     const bool input_left = more || n_susp > 0;
     /* the fullest pool that holds a whole step; once nothing is left to walk, the fullest pool */
     int c = -1;
@@ -2970,6 +2997,9 @@ __global__ __launch_bounds__(PT_BOUNCE_THREADS, PT_BOUNCE_WAVES) void k_bounce(P
       }
 #undef PT_POOL_STEP
       if (c != PT_CAT_MISS && !last_bounce) pt_pool_push<EMIT>(sc, out, so, lds_out);
+      if (PT_DIAG == 6) PT_TM5(c_floor);
+      else PT_TM5(c_prims);
+      if (DIAG_T) c_filter[0] += (lane == 0);
       continue;
     }
     if (!input_left) break;
@@ -3012,7 +3042,7 @@ __global__ __launch_bounds__(PT_BOUNCE_THREADS, PT_BOUNCE_WAVES) void k_bounce(P
         }
       }
     }
-    if (COUNT && valid && !resume) c_seg++;
+    if (COUNT && !DIAG_T && valid && !resume) c_seg++;
     PtTailCtl tc;
     tc.min_active = (TAIL && more) ? PT_TAIL_CUT : 0; /* the last chunks of a wave run to completion */
     tc.resume = resume && valid;
@@ -3023,8 +3053,11 @@ __global__ __launch_bounds__(PT_BOUNCE_THREADS, PT_BOUNCE_WAVES) void k_bounce(P
     tc.v = __hiloint2double((int)parked_uv.w, (int)parked_uv.z);
     tc.unfinished = false;
     PtTraceResult r;
+    PT_TM5(c_floor);
     if (PRIMARY) r = pt_trace_packet<MODE, COUNT, true, true>(sc, sv, (uint32_t*)stack, valid, o, d, c_nodes, c_prims, c_floor, c_filter);
-    else r = pt_trace_ray<MODE, COUNT, false, StackT, true, PT_BOUNCE_DIV_LOOP(MODE)>(sc, sv, stack, o, d, c_nodes, c_prims, c_floor, valid, TAIL ? &tc : nullptr, c_filter);
+    else r = pt_trace_ray<MODE, COUNT, false, StackT, true, PT_BOUNCE_DIV_LOOP(MODE)>(sc, sv, stack, o, d, c_nodes, c_prims, c_floor, valid, TAIL ? &tc : nullptr, DIAG_T ? nullptr : c_filter);
+    PT_TM5(c_nodes);
+    if (DIAG_T) c_filter[1] += (lane == 0);
     const bool park = TAIL && tc.unfinished;
     const bool done = valid && !park;
     int cat = PT_CAT_NONE;
@@ -3034,7 +3067,7 @@ __global__ __launch_bounds__(PT_BOUNCE_THREADS, PT_BOUNCE_WAVES) void k_bounce(P
       if (MODE == PT_MODE_ARRAY && sc.has_triangles) {
         if (!PT_RECOMPUTE_HIT) hits.tuv[i] = make_double4(r.t, r.u, r.v, 0.0); /* (else the shade step recomputes it: PtHits) */
       } else hits.t[i] = r.t;
-      cat = r.slot < 0 ? PT_CAT_MISS : (int)sc.slot_cat[r.slot];
+      cat = r.slot < 0 ? PT_CAT_MISS : (int)(PT_LDS_CAT ? sv.cat : sc.slot_cat)[r.slot];
     }
 #pragma unroll
     for (int k = 0; k < PT_N_SHADE_CAT; ++k) {
@@ -3065,6 +3098,12 @@ __global__ __launch_bounds__(PT_BOUNCE_THREADS, PT_BOUNCE_WAVES) void k_bounce(P
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #endif
   }
+  if (DIAG_T) {
+    PT_TM5(c_floor);
+    c_seg = (lane == 0) ? tm_last - tm_begin : 0ull;
+    if (lane != 0) c_nodes = c_prims = c_floor = 0ull; /* wave-uniform quantities: one lane's copy */
+  }
+#undef PT_TM5
   if (COUNT && !(PT_DIAG != 0 && PRIMARY)) { /* (diagnostic builds measure the queued rays' launches only) */
     c_nodes = pt_wave_sum(c_nodes);
     c_prims = pt_wave_sum(c_prims);
