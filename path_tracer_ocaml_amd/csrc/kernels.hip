@@ -421,6 +421,7 @@ struct PtSceneView {
   const double* sph;
   const double* tri;
   const uint8_t* kind;
+  const double* nodes64; /* LDS-resident scenes with PtSceneDev.lds_nodes64: six binary64 bounds per node in LDS, else null */
   const uint8_t* cat; /* the slots' shading categories: the LDS copy on LDS-resident scenes (k_bounce files a finished ray by it right
                          after the walk: from global memory that one byte was a ~1 us round trip in every chunk's chain) */
   /* scenes walked from HBM / L2: the first n_floor_lds floor triangles (ganesha's Floor, tested before the tree for EVERY ray,
@@ -642,13 +643,14 @@ struct PtTraverser {
   /* the reference's own arithmetic on the binary64 node `np` (the filter could not decide): 1 / d again -- the same three
    * divisions as Ray.create, opaque to the optimiser, or it hoists them out of the walk and keeps six more registers live
    * across the hot loop */
-  __device__ __forceinline__ bool slab64(const PtNode* np) const {
+  __device__ __forceinline__ bool slab64(const double* nb /* mn.xyz, mx.xyz */) const {
     double qx = d.x, qy = d.y, qz = d.z;
     asm volatile("" : "+v"(qx), "+v"(qy), "+v"(qz));
     const V3 inv64 = v3(1.0 / qx, 1.0 / qy, 1.0 / qz);
-    return (!(pt_isfinite(inv64.x) && pt_isfinite(inv64.y) && pt_isfinite(inv64.z))) ? pt_slab_hit_exact(np->mn, o, inv64, 0.0, r.t)
-                                                                                     : pt_slab_hit_fast<ORIGIN_ZERO>(np->mn, o, inv64, 0.0, r.t);
+    return (!(pt_isfinite(inv64.x) && pt_isfinite(inv64.y) && pt_isfinite(inv64.z))) ? pt_slab_hit_exact(nb, o, inv64, 0.0, r.t)
+                                                                                     : pt_slab_hit_fast<ORIGIN_ZERO>(nb, o, inv64, 0.0, r.t);
   }
+  __device__ __forceinline__ bool slab64(const PtNode* np) const { return slab64(np->mn); }
   /* What the generic u = hi - lo cannot decide although it is certain: ONE axis k whose slab interval [near_k, far_k] lies
    * inside the other two axes' intervals and inside [0, t_max] by the margin.  Then the reference's lo IS near_k and its hi IS
    * far_k, and near_k <= far_k holds by construction (the min and the max of the same two products): a hit, however small
@@ -693,7 +695,8 @@ struct PtTraverser {
           if (nested) hit = true;
           else {
             if (COUNT) n_undecided++;
-            hit = slab64(sv.nodes + (nd - sv.swz_root) / PT_SWZ_NODE_BYTES);
+            const uint32_t k64 = (nd - sv.swz_root) / PT_SWZ_NODE_BYTES;
+            hit = sv.nodes64 ? slab64(sv.nodes64 + (size_t)k64 * 6u) : slab64(sv.nodes + k64); /* (wave-uniform choice) */
           }
           if (COUNT && __ballot(!nested) != 0 && pt_lane() == __ffsll((long long)__ballot(1)) - 1) n_wave_fallbacks++;
         }
@@ -1395,6 +1398,7 @@ __device__ __forceinline__ PtSceneView pt_scene_view(const PtSceneDev& sc, unsig
   sv.tri = sc.tri;
   sv.kind = sc.slot_kind;
   sv.cat = sc.slot_cat;
+  sv.nodes64 = nullptr;
 #if PT_LEAF_PREFETCH
   if (!LDS_SCENE && sc.all_triangles) sv.kind = nullptr; /* PtTraverser::packet: the pipelined triangle loop */
 #endif
@@ -1410,6 +1414,8 @@ __device__ __forceinline__ PtSceneView pt_scene_view(const PtSceneDev& sc, unsig
     uint8_t* l_kind = (uint8_t*)(lds_raw + off);
     if (MODE == PT_MODE_ARRAY) off += ((size_t)total_slots + 15) & ~(size_t)15;
     uint8_t* l_cat = (uint8_t*)(lds_raw + off);
+    off += ((size_t)total_slots + 15) & ~(size_t)15;
+    double* l_n64 = (double*)(lds_raw + off);
     /* nodes: the binary32 filter image (PT_SWZ_NODE_BYTES each); links become byte offsets into it -- with PT_SWZ_SIGNSEL,
      * absolute LDS addresses (layout 3 above) */
 #if PT_SWZ_SIGNSEL
@@ -1464,6 +1470,9 @@ __device__ __forceinline__ PtSceneView pt_scene_view(const PtSceneDev& sc, unsig
       for (int k = threadIdx.x; k < total_slots; k += blockDim.x) l_kind[k] = sc.slot_kind[k];
     }
     for (int k = threadIdx.x; k < total_slots; k += blockDim.x) l_cat[k] = sc.slot_cat[k];
+    if (sc.lds_nodes64) /* (workgroup-uniform) mn.xyz, mx.xyz: the first 48 bytes of a PtNode */
+      for (int k = threadIdx.x; k < sc.n_nodes * 3; k += blockDim.x)
+        ((double2*)l_n64)[k] = ((const double2*)(sc.nodes + k / 3))[k % 3];
     __syncthreads();
     sv.swz_nodes = l_nodes;
     sv.swz_root = nbase;
@@ -1471,6 +1480,7 @@ __device__ __forceinline__ PtSceneView pt_scene_view(const PtSceneDev& sc, unsig
     sv.tri = l_tri;
     sv.kind = l_kind;
     sv.cat = l_cat;
+    if (sc.lds_nodes64) sv.nodes64 = l_n64;
   }
   return sv;
 }

@@ -102,6 +102,10 @@ struct PtSceneDev {
   int32_t has_triangles;
   int32_t has_emit;
   int32_t has_checker;
+  /* LDS-resident scenes: 1 = the LDS image also carries every node's six binary64 bounds (48 bytes per node) for the tests the
+   * binary32 filter leaves undecided -- 2 % (Shirley) to 5.5 % (cornell) of a walk's wave steps, each of which otherwise waits for a
+   * global load.  Set by the host when the scene still fits LDS with them (scene_upload). */
+  int32_t lds_nodes64;
   const PtMaterial* materials;
   const PtTexture* textures;
   const PtShadeRec* slot_shade; /* per slot (padding slots zero) */

@@ -422,6 +422,7 @@ def test_random_configs_raw_sums_bitwise(P, oracle, seed, monkeypatch):
     monkeypatch.setenv("PTX_BIN_KEY", str(int(rng.integers(0, 3))))  # survivors binned by octant / elevation / reaches-the-tree's-box
     monkeypatch.setenv("PTX_FUSED", str(int(rng.integers(0, 3))))  # k_bounce for every bounce / all but the camera rays' / k_trace + shade kernels
     monkeypatch.setenv("PTX_BOUNCE_THREADS", str(int(rng.choice([0, 64, 192, 512]))))  # k_bounce workgroup size (0 = 1024)
+    monkeypatch.setenv("PTX_LDS_NODES64", str(int(rng.integers(0, 2))))  # LDS scenes: the undecided box tests' binary64 bounds from LDS / global memory
     monkeypatch.setenv("PTX_TRI_FRAME", str(int(rng.integers(0, 2))))  # per-triangle normal + rotations from the table / computed per hit
     o_scene = oracle.Scene(d.ptr, d)
     g_scene = P.Scene(d.ptr, 0, keepalive=d)
