@@ -2150,11 +2150,12 @@ __device__ __forceinline__ PtSurface pt_surface_hit(const PtSceneDev& sc, V3 o, 
     sf.tv = (uv[1] * w) + (uv[3] * u) + (uv[5] * v);
     sf.hit_front = v3_dot(d, g_normal) < 0.0;
     sf.normal = sf.hit_front ? g_normal : v3_neg(g_normal);
-    if (framed) { /* Shader_space.create of that normal: one of the slot's two precomputed rotations (PtSceneDev.tri_frame) */
-      const double* r = sc.tri_frame + (size_t)slot * PT_TRI_FRAME_DOUBLES + (sf.hit_front ? 4 : 8);
-      const double2 r0 = ((const double2*)r)[0], r1 = ((const double2*)r)[1];
-      sf.rot.r = r0.x;
-      sf.rot.v = v3(r0.y, r1.x, r1.y);
+    if (framed) { /* Shader_space.create of that normal: one of the slot's two precomputed rotations (PtSceneDev.tri_frame); both are
+                     requested with the normal -- a load that depends on hit_front would be one more round trip in the step's chain */
+      const double2* r = (const double2*)(sc.tri_frame + (size_t)slot * PT_TRI_FRAME_DOUBLES + 4);
+      const double2 f0 = r[0], f1 = r[1], b0 = r[2], b1 = r[3];
+      sf.rot.r = sf.hit_front ? f0.x : b0.x;
+      sf.rot.v = v3(sf.hit_front ? f0.y : b0.y, sf.hit_front ? f1.x : b1.x, sf.hit_front ? f1.y : b1.y);
       sf.omega_i = pt_quat_transform(sf.rot, v3_neg(d));
       return sf;
     }
@@ -2918,6 +2919,9 @@ __global__ __launch_bounds__(PT_POOL_THREADS, PT_SHADE_WAVES) void k_shade_pool(
 #ifndef PT_BOUNCE_MIN_CHUNKS
 #define PT_BOUNCE_MIN_CHUNKS 2 /* chunks per wave below which fewer workgroups take part (k_shade_pool: 16 -- there a chunk is a few microseconds) */
 #endif
+#ifndef PT_SHADE_LDS_GEOM
+#define PT_SHADE_LDS_GEOM 1 /* k_bounce's shade steps read slot kinds / spheres / triangles from the LDS image instead of global memory */
+#endif
 #ifndef PT_LDS_CAT
 #define PT_LDS_CAT 1 /* k_bounce reads a finished ray's shading category from the LDS copy (PtSceneView.cat); 0: from global memory */
 #endif
@@ -2952,6 +2956,14 @@ __global__ __launch_bounds__(PT_BOUNCE_THREADS, PT_BOUNCE_WAVES) void k_bounce(P
 #if PT_DIAG_FLOOR == 1
   if (gridDim.x > 0) return; /* diagnostic build: launch + the scene image in LDS, nothing else */
 #endif
+  /* the shade steps read the slots' kinds and geometry where the walk reads them: the LDS image (generic pointers: flat loads) */
+  static_assert(!PT_SHADE_LDS_GEOM || PT_LDS_SPH_DOUBLES == 4, "the shade step strides sphere records by 4 doubles");
+  PtSceneDev scl = sc;
+  if (PT_SHADE_LDS_GEOM) {
+    scl.slot_kind = sv.kind;
+    scl.sph = sv.sph;
+    scl.tri = sv.tri;
+  }
   uint2 (*pool)[128] = (uint2 (*)[128])(lds_raw + pool_off) + (size_t)wave * PT_N_SHADE_CAT;
   uint32_t cnt[PT_N_SHADE_CAT];
 #pragma unroll
@@ -2995,7 +3007,7 @@ __global__ __launch_bounds__(PT_BOUNCE_THREADS, PT_BOUNCE_WAVES) void k_bounce(P
       i = e.x;                                                                                                             \
       sl = (int)e.y;                                                                                                       \
     }                                                                                                                      \
-    pt_shade_entry<EMIT, PRIMARY, K>(sc, q, hits, contrib, alpha, bounce, last_bounce, g, i, live, so, ##__VA_ARGS__);    \
+    pt_shade_entry<EMIT, PRIMARY, K>(PT_SHADE_LDS_GEOM ? scl : sc, q, hits, contrib, alpha, bounce, last_bounce, g, i, live, so, ##__VA_ARGS__); \
   } break;
       switch (c) {
         PT_POOL_STEP(PT_CAT_MISS)
