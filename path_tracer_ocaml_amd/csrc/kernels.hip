@@ -2978,7 +2978,7 @@ __global__ __launch_bounds__(PT_BOUNCE_THREADS, PT_BOUNCE_WAVES) void k_bounce(P
    * in ticks of the 100 MHz clock summed over waves -- nodes = walks, prims = shade steps (with their pushes), floor = everything
    * else in the loop (chunk hand-out, ray loads, filing, parking), segments = the whole loop; undecided / fallback_steps = the
    * number of shade steps / walks */
-  constexpr bool DIAG_T = COUNT && (PT_DIAG == 5 || PT_DIAG == 6) && !PRIMARY; /* 6: prims = the walks' leaf phases instead of the shade steps */
+  constexpr bool DIAG_T = COUNT && (PT_DIAG == 5 || PT_DIAG == 6 || PT_DIAG == 7) && !PRIMARY; /* 6: prims = the walks' leaf phases instead of the shade steps; 7: prims = the pushes alone */
   unsigned long long tm_last = DIAG_T ? __builtin_readcyclecounter() : 0ull;
   const unsigned long long tm_begin = tm_last;
 #define PT_TM5(var) do { if (DIAG_T) { __builtin_amdgcn_sched_barrier(0); const unsigned long long now_ = __builtin_readcyclecounter(); (var) += now_ - tm_last; tm_last = now_; __builtin_amdgcn_sched_barrier(0); } } while (0)
@@ -3018,6 +3018,7 @@ __global__ __launch_bounds__(PT_BOUNCE_THREADS, PT_BOUNCE_WAVES) void k_bounce(P
         default: break;
       }
 #undef PT_POOL_STEP
+      if (PT_DIAG == 7) PT_TM5(c_floor);
       if (c != PT_CAT_MISS && !last_bounce) pt_pool_push<EMIT>(sc, out, so, lds_out);
       if (PT_DIAG == 6) PT_TM5(c_floor);
       else PT_TM5(c_prims);

@@ -18,12 +18,17 @@ if len(sys.argv) > 2:  # child: one library per process (PTX_LIB is read at impo
     life, walk, b, rest = st["segments"], st["nodes_tested"], st["prims_tested"], st["floor_tested"]
     if mode == 5:
         print(f"{name}: wave life {life / 1e8:.3f} s summed; walks {walk / life:.3f}  shade steps + pushes {b / life:.3f}  rest {rest / life:.3f}; "
-              f"{st['filter_fallback_steps']} walks of {walk / max(st['filter_fallback_steps'], 1) * 10:.0f} ns, "
-              f"{st['filter_undecided']} shade steps of {b / max(st['filter_undecided'], 1) * 10:.0f} ns")
+              f"{st['filter_fallback_steps']} walks of {walk / max(st['filter_fallback_steps'], 1) :.0f} clocks, "
+              f"{st['filter_undecided']} shade steps of {b / max(st['filter_undecided'], 1) :.0f} clocks")
+    elif mode == 7:
+        print(f"{name}: survivors' pushes (bin key, reservation, stores) {b / life:.3f} of a wave's life, {b / max(st['filter_undecided'], 1):.0f} clocks per shade step")
     else:
         print(f"{name}: of the walks' time, leaf phases (packet scan + roots / element tests) {b / max(walk, 1):.3f}, node loop + begin {1 - b / max(walk, 1):.3f}")
     sys.exit(0)
 name = sys.argv[1] if len(sys.argv) > 1 else "shirley"
-for mode in (5, 6):
-    env = dict(os.environ, PTX_LIB=os.path.join(ROOT, "build_variants", f"libptx_diag{mode}.so"))
+for mode in (5, 6, 7):
+    lib = os.path.join(ROOT, "build_variants", f"libptx_diag{mode}.so")
+    if not os.path.exists(lib):
+        continue
+    env = dict(os.environ, PTX_LIB=lib)
     subprocess.run([sys.executable, os.path.abspath(__file__), name, str(mode)], env=env, check=False)
