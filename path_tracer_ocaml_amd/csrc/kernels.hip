@@ -2978,7 +2978,7 @@ __global__ __launch_bounds__(PT_BOUNCE_THREADS, PT_BOUNCE_WAVES) void k_bounce(P
    * in ticks of the 100 MHz clock summed over waves -- nodes = walks, prims = shade steps (with their pushes), floor = everything
    * else in the loop (chunk hand-out, ray loads, filing, parking), segments = the whole loop; undecided / fallback_steps = the
    * number of shade steps / walks */
-  constexpr bool DIAG_T = COUNT && (PT_DIAG == 5 || PT_DIAG == 6 || PT_DIAG == 7) && !PRIMARY; /* 6: prims = the walks' leaf phases instead of the shade steps; 7: prims = the pushes alone */
+  constexpr bool DIAG_T = COUNT && (((PT_DIAG == 5 || PT_DIAG == 6 || PT_DIAG == 7) && !PRIMARY) || (PT_DIAG == 8 && PRIMARY)); /* 8: as 5, the camera rays' launches */ /* 6: prims = the walks' leaf phases instead of the shade steps; 7: prims = the pushes alone */
   unsigned long long tm_last = DIAG_T ? __builtin_readcyclecounter() : 0ull;
   const unsigned long long tm_begin = tm_last;
 #define PT_TM5(var) do { if (DIAG_T) { __builtin_amdgcn_sched_barrier(0); const unsigned long long now_ = __builtin_readcyclecounter(); (var) += now_ - tm_last; tm_last = now_; __builtin_amdgcn_sched_barrier(0); } } while (0)
@@ -3078,7 +3078,8 @@ __global__ __launch_bounds__(PT_BOUNCE_THREADS, PT_BOUNCE_WAVES) void k_bounce(P
     tc.unfinished = false;
     PtTraceResult r;
     PT_TM5(c_floor);
-    if (PRIMARY) r = pt_trace_packet<MODE, COUNT, true, true>(sc, sv, (uint32_t*)stack, valid, o, d, c_nodes, c_prims, c_floor, c_filter);
+    unsigned long long dg_n = 0, dg_p = 0, dg_f = 0; /* (diagnostic builds: the packet walk's own counters go nowhere) */
+    if (PRIMARY) r = pt_trace_packet<MODE, COUNT, true, true>(sc, sv, (uint32_t*)stack, valid, o, d, DIAG_T ? dg_n : c_nodes, DIAG_T ? dg_p : c_prims, DIAG_T ? dg_f : c_floor, DIAG_T ? nullptr : c_filter);
     else r = pt_trace_ray<MODE, COUNT, false, StackT, true, PT_BOUNCE_DIV_LOOP(MODE)>(sc, sv, stack, o, d, c_nodes, c_prims, c_floor, valid, TAIL ? &tc : nullptr, DIAG_T ? nullptr : c_filter);
     PT_TM5(c_nodes);
     if (DIAG_T) c_filter[1] += (lane == 0);
@@ -3128,7 +3129,7 @@ __global__ __launch_bounds__(PT_BOUNCE_THREADS, PT_BOUNCE_WAVES) void k_bounce(P
     if (lane != 0) c_nodes = c_prims = c_floor = 0ull; /* wave-uniform quantities: one lane's copy */
   }
 #undef PT_TM5
-  if (COUNT && !(PT_DIAG != 0 && PRIMARY)) { /* (diagnostic builds measure the queued rays' launches only) */
+  if (COUNT && !(PT_DIAG != 0 && (PRIMARY != (PT_DIAG == 8)))) { /* (diagnostic builds measure the queued rays' launches only; 8: the camera rays') */
     c_nodes = pt_wave_sum(c_nodes);
     c_prims = pt_wave_sum(c_prims);
     c_floor = pt_wave_sum(c_floor);

@@ -16,8 +16,8 @@ if len(sys.argv) > 2:  # child: one library per process (PTX_LIB is read at impo
     raw = torch.zeros((h, w, 3), dtype=torch.float64, device="cuda")
     st = sc.render_raw_device(P.render_params(w, h, spp, depth, count_work=True), raw.data_ptr())
     life, walk, b, rest = st["segments"], st["nodes_tested"], st["prims_tested"], st["floor_tested"]
-    if mode == 5:
-        print(f"{name}: wave life {life / 1e8:.3f} s summed; walks {walk / life:.3f}  shade steps + pushes {b / life:.3f}  rest {rest / life:.3f}; "
+    if mode in (5, 8):
+        print(f"{name}{' (camera rays)' if mode == 8 else ''}: wave life {life / 1e8:.3f} s summed; walks {walk / life:.3f}  shade steps + pushes {b / life:.3f}  rest {rest / life:.3f}; "
               f"{st['filter_fallback_steps']} walks of {walk / max(st['filter_fallback_steps'], 1) :.0f} clocks, "
               f"{st['filter_undecided']} shade steps of {b / max(st['filter_undecided'], 1) :.0f} clocks")
     elif mode == 7:
@@ -26,7 +26,7 @@ if len(sys.argv) > 2:  # child: one library per process (PTX_LIB is read at impo
         print(f"{name}: of the walks' time, leaf phases (packet scan + roots / element tests) {b / max(walk, 1):.3f}, node loop + begin {1 - b / max(walk, 1):.3f}")
     sys.exit(0)
 name = sys.argv[1] if len(sys.argv) > 1 else "shirley"
-for mode in (5, 6, 7):
+for mode in (5, 6, 7, 8):
     lib = os.path.join(ROOT, "build_variants", f"libptx_diag{mode}.so")
     if not os.path.exists(lib):
         continue
