@@ -2909,6 +2909,11 @@ __global__ __launch_bounds__(PT_POOL_THREADS, PT_SHADE_WAVES) void k_shade_pool(
 #ifndef PT_BOUNCE_THREADS
 #define PT_BOUNCE_THREADS 1024
 #endif
+#ifndef PT_BOUNCE_THREADS_GLOBAL
+#define PT_BOUNCE_THREADS_GLOBAL 1024 /* k_bounce workgroup on scenes walked from HBM / L2: nothing is shared but the output blocks and the chunk
+                                         hand-out, and the larger the group that shares them the better -- ganesha-like frame 28.4 (256) / 28.0 (512) /
+                                         26.1 ms (1024) against 28.95 ms for k_trace + k_shade_pool */
+#endif
 #ifndef PT_BOUNCE_WAVES
 #define PT_BOUNCE_WAVES 4 /* waves per SIMD asked of the register allocator (PT_BOUNCE_THREADS / 256); 768 threads / 3 waves: +16 % */
 #endif
@@ -2931,7 +2936,12 @@ __global__ __launch_bounds__(PT_POOL_THREADS, PT_SHADE_WAVES) void k_shade_pool(
 #ifndef PT_BOUNCE_FENCE_WG
 #define PT_BOUNCE_FENCE_WG 0 /* 1: workgroup-scope fences (s_waitcnt vmcnt(0)) around the wave's own hit / parked records instead of wavefront scope */
 #endif
-template <int MODE, bool COUNT, bool EMIT, bool PRIMARY>
+/* LDS_SCENE = false (round 5): the same kernel for scenes walked from HBM / L2 over the per-octant node image (PtThreadOctTag; the
+ * host launches it when PtSceneDev.nodes32o exists): the walk is k_trace's (threaded, binary32 filter, chunk cut at
+ * PT_TAIL_CUT_GLOBAL with the third parked word for 32-bit node indices and slots, camera rays walked one per lane and parked like
+ * any other), the pools and shade steps are the ones above, nothing of the scene is copied to LDS but the pre-tested floor
+ * triangles, and the hit slot no longer travels through memory between two launches. */
+template <int MODE, bool COUNT, bool EMIT, bool PRIMARY, bool LDS_SCENE = true>
 __global__ __launch_bounds__(PT_BOUNCE_THREADS, PT_BOUNCE_WAVES) void k_bounce(PtSceneDev sc, PtQueue q, PtHits hits, PtQueue out, PtContrib contrib,
                                                                  const double* __restrict__ alpha, int bounce, int last_bounce, PtGenParams g,
                                                                  uint32_t n_primary, int stack_depth, uint32_t pool_off, uint4* susp,
@@ -2940,8 +2950,8 @@ __global__ __launch_bounds__(PT_BOUNCE_THREADS, PT_BOUNCE_WAVES) void k_bounce(P
   __shared__ uint32_t lds_out[PT_POOL_BINS];
   __shared__ uint32_t lds_chunk_ctr, lds_done;
   const int lane = pt_lane(), wave = (int)(threadIdx.x >> 6), nw = (int)(blockDim.x >> 6);
-  typedef uint16_t StackT;
-  StackT* stack = (StackT*)(lds_raw + (size_t)wave * PT_WAVE_STACK_BYTES(true, StackT, stack_depth));
+  typedef typename std::conditional<LDS_SCENE, uint16_t, PtThreadOctTag>::type StackT;
+  StackT* stack = (StackT*)(lds_raw + (size_t)wave * PT_WAVE_STACK_BYTES(LDS_SCENE, StackT, stack_depth));
   const uint32_t n = PRIMARY ? n_primary : *q.count;
   const uint32_t total_chunks = (uint32_t)(((unsigned long long)n + PT_WAVE - 1) / PT_WAVE);
   uint32_t n_wg = total_chunks / (uint32_t)(PT_BOUNCE_MIN_CHUNKS * nw);
@@ -2952,14 +2962,23 @@ __global__ __launch_bounds__(PT_BOUNCE_THREADS, PT_BOUNCE_WAVES) void k_bounce(P
 #endif
   if (threadIdx.x == 0) { lds_chunk_ctr = 0u; lds_done = 0u; }
   if (threadIdx.x < PT_POOL_BINS) lds_out[threadIdx.x] = (PT_POOL_NO_BLOCK << 12) | (uint32_t)PT_POOL_BLOCK; /* "full": the first push brings a block */
-  const PtSceneView sv = pt_scene_view<MODE, true, StackT>(sc, lds_raw, stack_depth); /* ends with the workgroup's only barrier */
+  PtSceneView sv = pt_scene_view<MODE, LDS_SCENE, StackT>(sc, lds_raw, stack_depth); /* LDS_SCENE: ends with the workgroup's only barrier */
+  if (!LDS_SCENE) {
+    __shared__ double lds_floor[PT_FLOOR_LDS * 10];
+    if (MODE == PT_MODE_ARRAY && sc.n_floor > 0) { /* the pre-tested floor triangles: see PtSceneView.floor_lds */
+      sv.n_floor_lds = sc.n_floor < PT_FLOOR_LDS ? sc.n_floor : PT_FLOOR_LDS;
+      sv.floor_lds = (const __attribute__((address_space(3))) double*)lds_floor;
+      for (int k = threadIdx.x; k < sv.n_floor_lds * 10; k += blockDim.x) lds_floor[k] = sc.tri[(size_t)sc.n_slots * 10 + k];
+    }
+    __syncthreads(); /* the workgroup's only barrier */
+  }
 #if PT_DIAG_FLOOR == 1
   if (gridDim.x > 0) return; /* diagnostic build: launch + the scene image in LDS, nothing else */
 #endif
   /* the shade steps read the slots' kinds and geometry where the walk reads them: the LDS image (generic pointers: flat loads) */
   static_assert(!PT_SHADE_LDS_GEOM || PT_LDS_SPH_DOUBLES == 4, "the shade step strides sphere records by 4 doubles");
   PtSceneDev scl = sc;
-  if (PT_SHADE_LDS_GEOM) {
+  if (PT_SHADE_LDS_GEOM && LDS_SCENE) {
     scl.slot_kind = sv.kind;
     scl.sph = sv.sph;
     scl.tri = sv.tri;
@@ -2968,8 +2987,10 @@ __global__ __launch_bounds__(PT_BOUNCE_THREADS, PT_BOUNCE_WAVES) void k_bounce(P
   uint32_t cnt[PT_N_SHADE_CAT];
 #pragma unroll
   for (int k = 0; k < PT_N_SHADE_CAT; ++k) cnt[k] = 0u;
-  constexpr bool TAIL = PT_TAIL_CUT > 0 && !PRIMARY; /* camera rays walk as a packet (pt_trace_packet) and finish together */
+  constexpr int CUT = LDS_SCENE ? PT_TAIL_CUT : PT_TAIL_CUT_GLOBAL;
+  constexpr bool TAIL = CUT > 0 && !(PRIMARY && LDS_SCENE); /* LDS scenes: camera rays walk as a packet (pt_trace_packet) and finish together */
   constexpr bool TAIL_UV = TAIL && MODE == PT_MODE_ARRAY;
+  constexpr bool TAIL_W = TAIL && !LDS_SCENE; /* 32-bit node index and slot: a third 16 bytes (as in k_trace) */
   uint4* my_susp = susp + ((size_t)blockIdx.x * nw + wave) * (PT_WAVE * 3);
   uint32_t n_susp = 0; /* wave-uniform */
   bool more = true;    /* wave-uniform: the workgroup's share of the queue is not exhausted */
@@ -3007,7 +3028,7 @@ __global__ __launch_bounds__(PT_BOUNCE_THREADS, PT_BOUNCE_WAVES) void k_bounce(P
       i = e.x;                                                                                                             \
       sl = (int)e.y;                                                                                                       \
     }                                                                                                                      \
-    pt_shade_entry<EMIT, PRIMARY, K>(PT_SHADE_LDS_GEOM ? scl : sc, q, hits, contrib, alpha, bounce, last_bounce, g, i, live, so, ##__VA_ARGS__); \
+    pt_shade_entry<EMIT, PRIMARY, K>((PT_SHADE_LDS_GEOM && LDS_SCENE) ? scl : sc, q, hits, contrib, alpha, bounce, last_bounce, g, i, live, so, ##__VA_ARGS__); \
   } break;
       switch (c) {
         PT_POOL_STEP(PT_CAT_MISS)
@@ -3029,12 +3050,13 @@ __global__ __launch_bounds__(PT_BOUNCE_THREADS, PT_BOUNCE_WAVES) void k_bounce(P
     /* walk: 64 parked rays once enough have gathered (or nothing else is left), else the next chunk of the share */
     bool resume = false, valid = false;
     uint32_t i = 0;
-    uint4 parked = make_uint4(0, 0, 0, 0), parked_uv = make_uint4(0, 0, 0, 0);
-    if (TAIL && (n_susp > (uint32_t)(PT_WAVE - PT_TAIL_CUT) || (!more && n_susp > 0))) {
+    uint4 parked = make_uint4(0, 0, 0, 0), parked_uv = make_uint4(0, 0, 0, 0), parked_w = make_uint4(0, 0, 0, 0);
+    if (TAIL && (n_susp > (uint32_t)(PT_WAVE - CUT) || (!more && n_susp > 0))) {
       resume = true;
       valid = (uint32_t)lane < n_susp;
       if (valid) parked = my_susp[lane];
       if (TAIL_UV && valid) parked_uv = my_susp[PT_WAVE + lane];
+      if (TAIL_W && valid) parked_w = my_susp[2 * PT_WAVE + lane];
       i = parked.x;
       n_susp = 0;
     } else {
@@ -3068,10 +3090,10 @@ __global__ __launch_bounds__(PT_BOUNCE_THREADS, PT_BOUNCE_WAVES) void k_bounce(P
     }
     if (COUNT && !DIAG_T && valid && !resume) c_seg++;
     PtTailCtl tc;
-    tc.min_active = (TAIL && more) ? PT_TAIL_CUT : 0; /* the last chunks of a wave run to completion */
+    tc.min_active = (TAIL && more) ? CUT : 0; /* the last chunks of a wave run to completion */
     tc.resume = resume && valid;
-    tc.node = parked.y & 0xffffu;
-    tc.slot = (int)(parked.y >> 16) == 0xffff ? -1 : (int)(parked.y >> 16);
+    tc.node = TAIL_W ? parked_w.x : (parked.y & 0xffffu);
+    tc.slot = TAIL_W ? (int)parked_w.y : ((int)(parked.y >> 16) == 0xffff ? -1 : (int)(parked.y >> 16));
     tc.t = __hiloint2double((int)parked.w, (int)parked.z);
     tc.u = __hiloint2double((int)parked_uv.y, (int)parked_uv.x);
     tc.v = __hiloint2double((int)parked_uv.w, (int)parked_uv.z);
@@ -3079,8 +3101,8 @@ __global__ __launch_bounds__(PT_BOUNCE_THREADS, PT_BOUNCE_WAVES) void k_bounce(P
     PtTraceResult r;
     PT_TM5(c_floor);
     unsigned long long dg_n = 0, dg_p = 0, dg_f = 0; /* (diagnostic builds: the packet walk's own counters go nowhere) */
-    if (PRIMARY) r = pt_trace_packet<MODE, COUNT, true, true>(sc, sv, (uint32_t*)stack, valid, o, d, DIAG_T ? dg_n : c_nodes, DIAG_T ? dg_p : c_prims, DIAG_T ? dg_f : c_floor, DIAG_T ? nullptr : c_filter);
-    else r = pt_trace_ray<MODE, COUNT, false, StackT, true, PT_BOUNCE_DIV_LOOP(MODE)>(sc, sv, stack, o, d, c_nodes, c_prims, c_floor, valid, TAIL ? &tc : nullptr, DIAG_T ? nullptr : c_filter);
+    if constexpr (PRIMARY && LDS_SCENE) r = pt_trace_packet<MODE, COUNT, true, true>(sc, sv, (uint32_t*)stack, valid, o, d, DIAG_T ? dg_n : c_nodes, DIAG_T ? dg_p : c_prims, DIAG_T ? dg_f : c_floor, DIAG_T ? nullptr : c_filter);
+    else r = pt_trace_ray<MODE, COUNT, PRIMARY, StackT, LDS_SCENE, LDS_SCENE ? PT_BOUNCE_DIV_LOOP(MODE) : PT_TRACE_DIV_LOOP(false)>(sc, sv, stack, o, d, c_nodes, c_prims, c_floor, valid, TAIL ? &tc : nullptr, DIAG_T ? nullptr : c_filter);
     PT_TM5(c_nodes);
     if (DIAG_T) c_filter[1] += (lane == 0);
     const bool park = TAIL && tc.unfinished;
@@ -3092,7 +3114,7 @@ __global__ __launch_bounds__(PT_BOUNCE_THREADS, PT_BOUNCE_WAVES) void k_bounce(P
       if (MODE == PT_MODE_ARRAY && sc.has_triangles) {
         if (!PT_RECOMPUTE_HIT) hits.tuv[i] = make_double4(r.t, r.u, r.v, 0.0); /* (else the shade step recomputes it: PtHits) */
       } else hits.t[i] = r.t;
-      cat = r.slot < 0 ? PT_CAT_MISS : (int)(PT_LDS_CAT ? sv.cat : sc.slot_cat)[r.slot];
+      cat = r.slot < 0 ? PT_CAT_MISS : (int)((PT_LDS_CAT || !LDS_SCENE) ? sv.cat : sc.slot_cat)[r.slot]; /* (walks from HBM / L2: sv.cat is sc.slot_cat) */
     }
 #pragma unroll
     for (int k = 0; k < PT_N_SHADE_CAT; ++k) {
@@ -3107,6 +3129,7 @@ __global__ __launch_bounds__(PT_BOUNCE_THREADS, PT_BOUNCE_WAVES) void k_bounce(P
           const uint32_t k = n_susp + (uint32_t)__popcll(pm & ((1ull << lane) - 1ull));
           my_susp[k] = make_uint4(i, tc.node | ((uint32_t)(r.slot < 0 ? 0xffff : r.slot) << 16),
                                   (uint32_t)__double2loint(r.t), (uint32_t)__double2hiint(r.t));
+          if (TAIL_W) my_susp[2 * PT_WAVE + k] = make_uint4(tc.node, (uint32_t)r.slot, 0u, 0u);
           if (TAIL_UV)
             my_susp[PT_WAVE + k] = make_uint4((uint32_t)__double2loint(r.u), (uint32_t)__double2hiint(r.u), (uint32_t)__double2loint(r.v), (uint32_t)__double2hiint(r.v));
         }

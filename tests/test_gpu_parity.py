@@ -422,6 +422,7 @@ def test_random_configs_raw_sums_bitwise(P, oracle, seed, monkeypatch):
     monkeypatch.setenv("PTX_BIN_KEY", str(int(rng.integers(0, 3))))  # survivors binned by octant / elevation / reaches-the-tree's-box
     monkeypatch.setenv("PTX_FUSED", str(int(rng.integers(0, 3))))  # k_bounce for every bounce / all but the camera rays' / k_trace + shade kernels
     monkeypatch.setenv("PTX_BOUNCE_THREADS", str(int(rng.choice([0, 64, 192, 512]))))  # k_bounce workgroup size (0 = 1024)
+    monkeypatch.setenv("PTX_FUSED_GLOBAL", str(int(rng.integers(0, 2))))  # meshes walked from HBM / L2: k_bounce / k_trace + shade kernels
     monkeypatch.setenv("PTX_LDS_NODES64", str(int(rng.integers(0, 2))))  # LDS scenes: the undecided box tests' binary64 bounds from LDS / global memory
     monkeypatch.setenv("PTX_TRI_FRAME", str(int(rng.integers(0, 2))))  # per-triangle normal + rotations from the table / computed per hit
     o_scene = oracle.Scene(d.ptr, d)
@@ -487,6 +488,38 @@ def test_bounce_kernel_against_the_oracle(P, oracle, kind, fused, threads, wgs, 
     c = oracle.Scene(d.ptr, d).render(w, h, spp, depth, threads=8, want_raw=True, count=True)
     g = P.Scene(d.ptr, 0, keepalive=d)
     assert g.stats()["traversal_in_lds"] == 1
+    raw = torch.zeros((h, w, 3), dtype=torch.float64, device="cuda:0")
+    for streams in ("1", "2"):
+        monkeypatch.setenv("PTX_STREAMS", streams)
+        for count in (True, False):
+            raw.zero_()
+            st = g.render_raw_device(P.render_params(w, h, spp, depth, count_work=count, time_kernels=True, passes_per_batch=2), raw.data_ptr())
+            assert np.array_equal(bits(raw.cpu().numpy()), bits(c["raw"])), (streams, count)
+            if count:
+                for k in ("segments", "nodes_tested", "prims_tested", "floor_tested"):
+                    assert st[k] == c["counters"][k], k
+            n_batches = (spp + 1) // 2
+            kl = st["kernel_launches"]
+            assert kl["bounce"] == n_batches * (depth if fused == 2 else depth - 1), kl
+            assert kl["trace"] == kl["shade"] == (0 if fused == 2 else n_batches), kl
+    g.close()
+
+
+@pytest.mark.parametrize("fused,threads,wgs,n_tri", [(2, 0, 0, 40000), (2, 64, 4, 40000), (1, 128, 16, 12000), (2, 512, 3, 12000), (2, 1024, 0, 40000)])
+def test_bounce_kernel_on_a_mesh_walked_from_hbm(P, oracle, fused, threads, wgs, n_tri, monkeypatch):
+    """k_bounce<..., LDS_SCENE = false> (PTX_FUSED_GLOBAL=1): the walk from HBM / L2 over the per-octant node image, the pools and
+    the shade steps in one launch per bounce, camera rays included (fused = 2) -- parked camera rays are recomputed from their
+    index, parked walks carry 32-bit node indices.  Raw sums and every work counter equal the oracle's; ptx_stats shows k_bounce ran."""
+    torch = pytest.importorskip("torch")
+    monkeypatch.setenv("PTX_FUSED_GLOBAL", "1")
+    monkeypatch.setenv("PTX_FUSED", str(fused))
+    monkeypatch.setenv("PTX_BOUNCE_THREADS", str(threads))
+    monkeypatch.setenv("PTX_BOUNCE_WGS", str(wgs))
+    w, h, spp, depth = 384, 192, 6, 10
+    d = oracle.desc_ganesha_like(w, h, n_target=n_tri)
+    c = oracle.Scene(d.ptr, d).render(w, h, spp, depth, threads=8, want_raw=True, count=True)
+    g = P.Scene(d.ptr, 0, keepalive=d)
+    assert g.stats()["traversal_in_lds"] == 0
     raw = torch.zeros((h, w, 3), dtype=torch.float64, device="cuda:0")
     for streams in ("1", "2"):
         monkeypatch.setenv("PTX_STREAMS", streams)

@@ -8,7 +8,7 @@ rocprofv3 --kernel-trace --output-format csv -d $out -- python3 bench.py --steps
 python3 - "$out" <<'PY'
 import csv, glob, sys
 f=sorted(glob.glob(sys.argv[1]+'/*/*kernel_trace.csv'))[-1]
-rows=[r for r in csv.DictReader(open(f)) if r['Kernel_Name'].startswith(('void k_trace','void k_shade','void k_classify','k_accum'))]
+rows=[r for r in csv.DictReader(open(f)) if r['Kernel_Name'].startswith(('void k_trace','void k_shade','void k_bounce','void k_classify','k_accum'))]
 rows.sort(key=lambda r:int(r['Start_Timestamp']))
 # the timed frame = the 2nd of 3 renders (warmup, timed, count): pick launches by splitting on k_accum groups
 frames=[]; cur=[]
