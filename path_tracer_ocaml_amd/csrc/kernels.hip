@@ -454,6 +454,10 @@ __device__ __forceinline__ uint32_t pt_stack_pop(const PtThreadOctTag*, int) { r
 #ifndef PT_WALK_MIN
 #define PT_WALK_MIN 8
 #endif
+#ifndef PT_WALK_MIN_GLOBAL
+#define PT_WALK_MIN_GLOBAL 16 /* the same threshold for the walk from HBM / L2, where a node step is a round trip to the L2 and the leaf phase's
+                                 first loads are the longest waits of the walk: leaves are taken up sooner (ganesha-like frame 4: 28.1, 8: 26.4, 16: 25.8 ms) */
+#endif
 #ifndef PT_LEAF_PREFETCH
 #define PT_LEAF_PREFETCH 1 /* triangle-only scenes walked from HBM / L2: request triangle k + 1 before testing triangle k */
 #endif
@@ -1111,6 +1115,7 @@ __device__ __forceinline__ PtTraceResult pt_trace_ray(const PtSceneDev& sc, cons
                                                       bool valid = true, PtTailCtl* tc = nullptr,
                                                       unsigned long long* c_filter = nullptr) {
   PtTraverser<MODE, COUNT, ORIGIN_ZERO, StackT, SWZ> tr;
+  constexpr int WALK_MIN = SWZ ? PT_WALK_MIN : PT_WALK_MIN_GLOBAL;
   unsigned long long no_count = 0; /* lanes without a ray run begin() on a dummy ray: keep them out of the counters */
   /* a resumed walk has had its floor pre-test (its outcome is part of the parked state): not counted again */
   tr.begin(sc, sv, o, d, (valid && !(tc && tc->resume)) ? c_floor : no_count);
@@ -1137,7 +1142,7 @@ __device__ __forceinline__ PtTraceResult pt_trace_ray(const PtSceneDev& sc, cons
         tr.node_step(sv, stack, c_nodes, c_prims);
         if (__ballot(tr.leaf_n > 0) != 0) leaf_waiting = true;
         if (!tr.wants_node()) break;
-        if (leaf_waiting && pt_popc_mask(__builtin_amdgcn_ballot_w64(true)) < PT_WALK_MIN) break;
+        if (leaf_waiting && pt_popc_mask(__builtin_amdgcn_ballot_w64(true)) < WALK_MIN) break;
       }
      }
     } else {
@@ -1146,7 +1151,7 @@ __device__ __forceinline__ PtTraceResult pt_trace_ray(const PtSceneDev& sc, cons
        * already holds a leaf, intersect the pending packets first (the stragglers resume afterwards) */
       const unsigned long long wm = tr.wants_node_mask();
       if (wm == 0) break;
-      if (pt_popc_mask(wm) < PT_WALK_MIN && tr.holds_leaf_mask() != 0) break;
+      if (pt_popc_mask(wm) < WALK_MIN && tr.holds_leaf_mask() != 0) break;
       if (COUNT && PT_DIAG == 1 && !ORIGIN_ZERO) PT_DIAG_WAVE_SLOTS(c_floor);
       if (!tr.wants_node()) continue;
       tr.node_step(sv, stack, c_nodes, c_prims);
@@ -2934,7 +2939,8 @@ __global__ __launch_bounds__(PT_POOL_THREADS, PT_SHADE_WAVES) void k_shade_pool(
 #define PT_DIAG_FLOOR 0 /* diagnostic builds only: 1 = k_bounce returns once the scene image is in LDS, 2 = at once (the launch floor) */
 #endif
 #ifndef PT_BOUNCE_FENCE_WG
-#define PT_BOUNCE_FENCE_WG 0 /* 1: workgroup-scope fences (s_waitcnt vmcnt(0)) around the wave's own hit / parked records instead of wavefront scope */
+#define PT_BOUNCE_FENCE_WG 0 /* 1: always workgroup-scope fences (s_waitcnt vmcnt(0)) around the wave's own hit / parked records instead of wavefront
+                                scope; at run time: PTX_BOUNCE_FENCE_WG=1 (k_bounce's fence_wg argument) */
 #endif
 /* LDS_SCENE = false (round 5): the same kernel for scenes walked from HBM / L2 over the per-octant node image (PtThreadOctTag; the
  * host launches it when PtSceneDev.nodes32o exists): the walk is k_trace's (threaded, binary32 filter, chunk cut at
@@ -2945,7 +2951,7 @@ template <int MODE, bool COUNT, bool EMIT, bool PRIMARY, bool LDS_SCENE = true>
 __global__ __launch_bounds__(PT_BOUNCE_THREADS, PT_BOUNCE_WAVES) void k_bounce(PtSceneDev sc, PtQueue q, PtHits hits, PtQueue out, PtContrib contrib,
                                                                  const double* __restrict__ alpha, int bounce, int last_bounce, PtGenParams g,
                                                                  uint32_t n_primary, int stack_depth, uint32_t pool_off, uint4* susp,
-                                                                 PtCounters* counters) {
+                                                                 PtCounters* counters, int fence_wg) {
   extern __shared__ __attribute__((aligned(64))) unsigned char lds_raw[];
   __shared__ uint32_t lds_out[PT_POOL_BINS];
   __shared__ uint32_t lds_chunk_ctr, lds_done;
@@ -3138,13 +3144,16 @@ __global__ __launch_bounds__(PT_BOUNCE_THREADS, PT_BOUNCE_WAVES) void k_bounce(P
     }
     /* this wave's own stores (hit records, parked states, pool entries) before its own later loads of them: program order
      * is enough for that (one wave's vector memory instructions reach the L1 / L2 in order), the compiler must not move them */
-#if PT_BOUNCE_FENCE_WG
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-#else
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#endif
+    /* fence_wg (PTX_BOUNCE_FENCE_WG=1, wave-uniform): workgroup-scope fences instead -- every store of the turn is waited for
+     * (s_waitcnt vmcnt(0)) before the wave goes on.  The safety net should the in-order assumption ever fail on some part; the
+     * parity tests run both (tests/test_gpu_parity.py). */
+    if (PT_BOUNCE_FENCE_WG || fence_wg) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    } else {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
   }
   if (DIAG_T) {
     PT_TM5(c_floor);

@@ -79,7 +79,21 @@ def test_bench_starts_its_own_ranks(world, workload):
     lines = _json_lines(r.stdout)
     assert len(lines) == 1, r.stdout
     assert lines[0]["n_gpus"] == world and lines[0]["steps"] == 2 and lines[0]["warmup"] == 1
-    assert lines[0]["value"] is None and lines[0]["rehearsal"]["bands_arrived_in_place"] is True
+    line = lines[0]
+    assert line["value"] is None and line["rehearsal"]["bands_arrived_in_place"] is True
+    # the N > 1 line is self-proving: what RCCL (here: gloo) saw, the timed frame's parity slot, the CPU leg and -- on the headline
+    # workload -- the configuration the scaling target is quoted on, timed across the same ranks (all null-valued in a rehearsal)
+    col = line["collective"]
+    assert col["world"] == world and col["backend"] == "gloo" and len(col["render_ms_per_rank"]) == world
+    assert col["rank0_gather_ms"] > 0 and col["bytes_into_rank0_per_step"] == (world - 1) * col["bytes_per_peer_per_step"] > 0
+    assert set(line["parity"]) >= {"timed_frame", "rel_linf_vs_cpu_ref", "tolerance"} and line["parity"]["timed_frame"]["pixels"] == 64
+    assert line["cpu_baseline"]["value"] > 0 and line["cpu_baseline"]["cores"] >= 1 and line["cpu_baseline"]["kind"] == "port"
+    if workload == "shirley_1080p_spp64_d8":
+        w5 = line["workloads"]["shirley_4k_spp256_d8"]
+        assert w5["n_gpus"] == world and w5["steps"] == 3 and w5["warmup"] == 1 and w5["samples_per_step"] == 3840 * 2160 * 256
+        assert "parity" in w5 and w5["collective"]["world"] == world and len(w5["collective"]["render_ms_per_rank"]) == world
+    else:
+        assert "workloads" not in line
 
 
 def test_self_launched_ranks_refuse_to_run_without_a_gpu():

@@ -422,6 +422,7 @@ def test_random_configs_raw_sums_bitwise(P, oracle, seed, monkeypatch):
     monkeypatch.setenv("PTX_BIN_KEY", str(int(rng.integers(0, 3))))  # survivors binned by octant / elevation / reaches-the-tree's-box
     monkeypatch.setenv("PTX_FUSED", str(int(rng.integers(0, 3))))  # k_bounce for every bounce / all but the camera rays' / k_trace + shade kernels
     monkeypatch.setenv("PTX_BOUNCE_THREADS", str(int(rng.choice([0, 64, 192, 512]))))  # k_bounce workgroup size (0 = 1024)
+    monkeypatch.setenv("PTX_BOUNCE_FENCE_WG", str(int(rng.integers(0, 2))))  # k_bounce: wavefront- / workgroup-scope fences around a wave's own records
     monkeypatch.setenv("PTX_FUSED_GLOBAL", str(int(rng.integers(0, 2))))  # meshes walked from HBM / L2: k_bounce / k_trace + shade kernels
     monkeypatch.setenv("PTX_LDS_NODES64", str(int(rng.integers(0, 2))))  # LDS scenes: the undecided box tests' binary64 bounds from LDS / global memory
     monkeypatch.setenv("PTX_TRI_FRAME", str(int(rng.integers(0, 2))))  # per-triangle normal + rotations from the table / computed per hit
@@ -470,9 +471,10 @@ def test_tail_cut_and_threaded_walk_under_small_grids(P, oracle, kind, block, wg
     g.close()
 
 
+@pytest.mark.parametrize("fence_wg", [0, 1])
 @pytest.mark.parametrize("kind,fused,threads,wgs", [("shirley", 2, 0, 0), ("shirley", 2, 64, 4), ("shirley", 1, 256, 16), ("shirley_no_simd", 2, 128, 8),
                                                      ("cornell", 2, 0, 0), ("cornell", 2, 64, 2), ("cornell", 1, 512, 3)])
-def test_bounce_kernel_against_the_oracle(P, oracle, kind, fused, threads, wgs, monkeypatch):
+def test_bounce_kernel_against_the_oracle(P, oracle, kind, fused, threads, wgs, fence_wg, monkeypatch):
     """k_bounce -- the default for scenes whose tree fits LDS: a bounce's walk and its pooled shade in ONE launch -- must be the
     path that runs (ptx_stats counts its launches apart from k_trace / k_shade_pool) and give the oracle's raw sums and work
     counters bit for bit.  Small workgroups and a handful of them give every wave hundreds of chunks: many rounds of parking
@@ -482,6 +484,7 @@ def test_bounce_kernel_against_the_oracle(P, oracle, kind, fused, threads, wgs, 
     monkeypatch.setenv("PTX_FUSED", str(fused))
     monkeypatch.setenv("PTX_BOUNCE_THREADS", str(threads))
     monkeypatch.setenv("PTX_BOUNCE_WGS", str(wgs))
+    monkeypatch.setenv("PTX_BOUNCE_FENCE_WG", str(fence_wg))  # 1: the workgroup-scope fences (the safety net of the wave's own store -> load order)
     w, h, spp, depth = 384, 192, 6, 10
     d = {"shirley": lambda: oracle.desc_shirley(w, h), "shirley_no_simd": lambda: oracle.desc_shirley(w, h, no_simd=True),
          "cornell": lambda: oracle.desc_cornell(w, h)}[kind]()

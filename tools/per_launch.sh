@@ -4,7 +4,7 @@ export TMPDIR=/tmp
 out=$1; shift
 for kv in "$@"; do export "$kv"; done
 export PTX_STREAMS=${PTX_STREAMS:-1}
-rocprofv3 --kernel-trace --output-format csv -d $out -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline ${BENCH_ARGS} > $out.log 2>&1
+rocprofv3 --kernel-trace --output-format csv -d $out -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-workloads ${BENCH_ARGS} > $out.log 2>&1
 python3 - "$out" <<'PY'
 import csv, glob, sys
 f=sorted(glob.glob(sys.argv[1]+'/*/*kernel_trace.csv'))[-1]

@@ -4,7 +4,7 @@ export TMPDIR=/tmp
 export PTX_STREAMS=1
 export PTX_LIB=$PWD/build_variants/libptx_$1.so
 mkdir -p "$(dirname "$2")"
-rocprofv3 --pmc $3 --output-format csv -d $2 -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline ${4:+--workload $4} > $2.log 2>&1
+rocprofv3 --pmc $3 --output-format csv -d $2 -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-workloads ${4:+--workload $4} > $2.log 2>&1
 python3 - "$2" <<'PY'
 import csv, collections, glob, sys
 f=sorted(glob.glob(sys.argv[1]+'/*/*counter_collection.csv'))[-1]

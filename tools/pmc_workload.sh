@@ -1,7 +1,7 @@
 #!/bin/bash
 # usage: tools/pmc_workload.sh <workload> <outdir> "<counters>"   (one rocprofv3 --pmc pass; prints per-kernel sums)
 export TMPDIR=/tmp
-rocprofv3 --pmc $3 --output-format csv -d $2 -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --workload $1 > $2.log 2>&1
+rocprofv3 --pmc $3 --output-format csv -d $2 -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-workloads --workload $1 > $2.log 2>&1
 python3 - "$2" <<'PY'
 import csv, collections, glob, sys
 f=glob.glob(sys.argv[1]+'/*/*counter_collection.csv')[0]
