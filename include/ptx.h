@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define PTX_ABI_VERSION 5
+#define PTX_ABI_VERSION 6
 
 /* ---- materials: Material.t, path_tracer/src/material.ml:3-14 ---- */
 #define PTX_MAT_LAMBERTIAN 0 /* Lambertian of Texture.t */
@@ -185,6 +185,10 @@ typedef struct ptx_stats {
    * access (the runtime stages through host memory).  Replicas that share the root's device count in neither. */
   int32_t peer_copies;
   int32_t staged_copies;
+  /* if count_work: launches of the one-kernel-per-bounce path that found their input small enough (PTX_SOLO_ENTRIES) to run all
+   * remaining bounces of their batch by themselves; the batch's later launches return at once (ABI 6) */
+  int32_t solo_launches;
+  int32_t reserved_stats;
 } ptx_stats;
 
 /* ---- progressive photon mapping (progressive-photon-map/src/progressive_photon_map.ml) ---- */

@@ -130,7 +130,7 @@ def stats_dict(st):
         "leaf_slots": st.leaf_slots, "build_ms": st.build_ms,
         "traversal_in_lds": bool(st.traversal_in_lds), "bvh_built_on_gpu": bool(st.bvh_built_on_gpu),
         "filter_undecided": st.filter_undecided, "filter_fallback_steps": st.filter_fallback_steps,
-        "peer_copies": st.peer_copies, "staged_copies": st.staged_copies,
+        "peer_copies": st.peer_copies, "staged_copies": st.staged_copies, "solo_launches": st.solo_launches,
     }
 
 

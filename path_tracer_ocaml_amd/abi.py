@@ -69,6 +69,7 @@ class Stats(C.Structure):
         ("build_ms", C.c_double), ("traversal_in_lds", C.c_int32), ("bvh_built_on_gpu", C.c_int32),
         ("filter_undecided", C.c_int64), ("filter_fallback_steps", C.c_int64),
         ("peer_copies", C.c_int32), ("staged_copies", C.c_int32),
+        ("solo_launches", C.c_int32), ("reserved_stats", C.c_int32),
     ]
 
 

@@ -56,6 +56,10 @@ struct PtHits {
    * (cornell's bounce launches, TCC counters: 2.7 line requests per segment reach the L2, 2.4 miss): ~60 vector instructions
    * against a third of the kernel's memory traffic. */
   double4* tuv;
+  /* k_bounce running the remaining bounces of a batch in one launch (PtSolo): its workgroups are at DIFFERENT bounces at the same
+   * time, and entry i of the even queue and entry i of the odd queue would share t[i] -- bounce b keeps its distances at
+   * t + (b & 1) * t_parity_stride there (0: `t` holds one array only and no launch runs solo). */
+  size_t t_parity_stride;
 };
 #ifndef PT_RECOMPUTE_HIT
 #define PT_RECOMPUTE_HIT 1
@@ -115,6 +119,7 @@ __device__ __forceinline__ void pt_q_store(const PtQueue& q, uint32_t i, V3 o, V
 struct PtCounters { /* device-side work counters (count_work) */
   unsigned long long segments, nodes, prims, floor;
   unsigned long long undecided, fallback_steps; /* binary32 filter: lane tests handed to the binary64 code, wave steps that ran it */
+  unsigned long long solo;                      /* k_bounce launches that ran their batch's remaining bounces by themselves (PtSolo) */
 };
 
 /* ------------------------------------------------------------------ small device helpers */
@@ -2693,8 +2698,11 @@ __global__ __launch_bounds__(PT_SHADE_BLOCK, PT_SHADE_WAVES) void k_shade(PtScen
 #endif
 #define PT_POOL_NO_BLOCK 0xfffffu
 
+/* blk_list / blk_n (LDS, or null): every block this workgroup takes from the output queue is also noted there (PtSolo: the workgroup
+ * reads its own survivors back in the next bounce of the same launch) */
 template <bool EMIT>
-__device__ __forceinline__ void pt_pool_push(const PtSceneDev& sc, const PtQueue& out, const PtShadeOut& so, uint32_t* lds_out) {
+__device__ __forceinline__ void pt_pool_push(const PtSceneDev& sc, const PtQueue& out, const PtShadeOut& so, uint32_t* lds_out,
+                                             uint32_t* blk_list = nullptr, uint32_t* blk_n = nullptr) {
   const int lane = pt_lane();
   const int bin = pt_bin_key<PT_POOL_BINS>(sc, so.n_o, so.n_d);
   if (__ballot(so.keep) == 0) return;
@@ -2723,7 +2731,10 @@ __device__ __forceinline__ void pt_pool_push(const PtSceneDev& sc, const PtQueue
         /* this reservation crosses the end of the block (or finds it exactly full, or finds no block yet): fill it up and
          * bring the next one.  Everybody else sees pos > PT_POOL_BLOCK until the new word is stored. */
         uint32_t nb = 0;
-        if (lane == 0) nb = atomicAdd(out.count, (uint32_t)PT_POOL_BLOCK) / (uint32_t)PT_POOL_BLOCK;
+        if (lane == 0) {
+          nb = atomicAdd(out.count, (uint32_t)PT_POOL_BLOCK) / (uint32_t)PT_POOL_BLOCK;
+          if (blk_list) blk_list[__hip_atomic_fetch_add(blk_n, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)] = nb;
+        }
         nb = (uint32_t)__builtin_amdgcn_readfirstlane((int)nb);
         const uint32_t h = (uint32_t)PT_POOL_BLOCK - pos;
         if (lane == 0) __hip_atomic_store(lds_out + b, (nb << 12) | (k - h), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -2947,14 +2958,38 @@ __global__ __launch_bounds__(PT_POOL_THREADS, PT_SHADE_WAVES) void k_shade_pool(
  * PT_TAIL_CUT_GLOBAL with the third parked word for 32-bit node indices and slots, camera rays walked one per lane and parked like
  * any other), the pools and shade steps are the ones above, nothing of the scene is copied to LDS but the pre-tested floor
  * triangles, and the hit slot no longer travels through memory between two launches. */
+/* SOLO (round 5): the small launches at the end of a batch.  Once a bounce's input has shrunk to PtSolo.max_entries queue entries, a
+ * launch is a fixed cost -- the gap to the previous launch, the scene image built in LDS again, a handful of waves with one chunk
+ * each and their drain -- and a frame of few pixels (one rank's share of an 8-rank job, the reference's 600 x 300 command) consists
+ * of little else: 14 of its 16 launches per batch sat on that floor.  Paths are independent, so nothing requires the bounces of
+ * DIFFERENT workgroups to stay in step: the first launch that finds its input that small runs ALL remaining bounces -- every
+ * workgroup keeps its static share, notes the output blocks it takes (pt_pool_push), and after a workgroup barrier reads exactly
+ * those blocks back as the next bounce's input, the scene image still in LDS.  It leaves its bounce number + 1 in PtSolo.flag; the
+ * batch's later launches find it and return at once.  Workgroups drift apart in bounce number, so nothing written during the
+ * launch may be overwritten during it: each of the two queue buffers hands out blocks from ONE cursor for the whole launch (the
+ * buffer that holds the launch's input starts behind it), and the launch runs solo only if the buffers are large enough for
+ * every remaining bounce's survivors and holes in the worst case.  Same walks, same shade steps, same sampler dimensions per bounce: the
+ * results do not depend on the order of a queue, so they are the step-by-step launches' bit for bit. */
+struct PtSolo {
+  uint32_t* flag;       /* per batch, zero at its start; null = never run solo */
+  uint32_t max_entries; /* run solo when the input queue holds at most this many entries (0 = never) */
+  int32_t max_bounces;
+  uint32_t cap_entries; /* capacity of each of the two queues, in entries */
+};
+#ifndef PT_SOLO_MAX_BLOCKS
+#define PT_SOLO_MAX_BLOCKS 256 /* output blocks a workgroup can note per bounce; a launch whose shares could need more does not run solo */
+#endif
 template <int MODE, bool COUNT, bool EMIT, bool PRIMARY, bool LDS_SCENE = true>
 __global__ __launch_bounds__(PT_BOUNCE_THREADS, PT_BOUNCE_WAVES) void k_bounce(PtSceneDev sc, PtQueue q, PtHits hits, PtQueue out, PtContrib contrib,
                                                                  const double* __restrict__ alpha, int bounce, int last_bounce, PtGenParams g,
                                                                  uint32_t n_primary, int stack_depth, uint32_t pool_off, uint4* susp,
-                                                                 PtCounters* counters, int fence_wg) {
+                                                                 PtCounters* counters, int fence_wg, PtSolo solo) {
   extern __shared__ __attribute__((aligned(64))) unsigned char lds_raw[];
   __shared__ uint32_t lds_out[PT_POOL_BINS];
   __shared__ uint32_t lds_chunk_ctr, lds_done;
+  constexpr bool SOLO = !PRIMARY && PT_DIAG == 0 && PT_DIAG_FLOOR == 0;
+  __shared__ uint32_t lds_blk[SOLO ? 2 : 1][SOLO ? PT_SOLO_MAX_BLOCKS : 1]; /* the blocks this workgroup wrote in the bounce before / is writing now */
+  __shared__ uint32_t lds_nblk[2];
   const int lane = pt_lane(), wave = (int)(threadIdx.x >> 6), nw = (int)(blockDim.x >> 6);
   typedef typename std::conditional<LDS_SCENE, uint16_t, PtThreadOctTag>::type StackT;
   StackT* stack = (StackT*)(lds_raw + (size_t)wave * PT_WAVE_STACK_BYTES(LDS_SCENE, StackT, stack_depth));
@@ -2962,13 +2997,31 @@ __global__ __launch_bounds__(PT_BOUNCE_THREADS, PT_BOUNCE_WAVES) void k_bounce(P
   const uint32_t total_chunks = (uint32_t)(((unsigned long long)n + PT_WAVE - 1) / PT_WAVE);
   uint32_t n_wg = total_chunks / (uint32_t)(PT_BOUNCE_MIN_CHUNKS * nw);
   n_wg = n_wg < 1u ? 1u : (n_wg > gridDim.x ? gridDim.x : n_wg);
+  bool solo_on = false; /* launch-uniform */
+  if (SOLO && solo.flag != nullptr) {
+    const uint32_t f = __hip_atomic_load(solo.flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (f != 0u && f != (uint32_t)bounce + 1u) return; /* an earlier launch of this batch ran (or is the one running) this bounce */
+    /* the largest share of this launch in output blocks: runs of PT_POOL_RUN chunks dealt round-robin, every entry a survivor, one
+     * part-filled block per bin */
+    const uint32_t runs = (total_chunks + PT_POOL_RUN - 1u) / PT_POOL_RUN;
+    const uint32_t share_blocks = ((runs + n_wg - 1u) / n_wg) * PT_POOL_RUN * PT_WAVE / PT_POOL_BLOCK + PT_POOL_BINS;
+    /* each buffer takes the output of every second remaining bounce: at most the launch's input + one part-filled block per
+     * (workgroup, bin) each time, the input's buffer behind the input */
+    const unsigned long long per_bounce = (unsigned long long)n + (unsigned long long)n_wg * PT_POOL_BINS * PT_POOL_BLOCK;
+    const unsigned long long worst = (unsigned long long)((solo.max_bounces - bounce) / 2 + 1) * per_bounce + (unsigned long long)n + PT_POOL_BLOCK;
+    solo_on = !last_bounce && n <= solo.max_entries && share_blocks <= (uint32_t)PT_SOLO_MAX_BLOCKS && worst <= (unsigned long long)solo.cap_entries;
+    if (solo_on && blockIdx.x == 0 && threadIdx.x == 0) {
+      __hip_atomic_store(solo.flag, (uint32_t)bounce + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (COUNT) atomicAdd(&counters->solo, 1ull);
+    }
+  }
   if (blockIdx.x >= n_wg) return; /* workgroup-uniform */
 #if PT_DIAG_FLOOR == 2
   if (gridDim.x > 0) return; /* diagnostic build (tools/README.md): what a launch costs before it does anything */
 #endif
-  if (threadIdx.x == 0) { lds_chunk_ctr = 0u; lds_done = 0u; }
+  if (threadIdx.x == 0) { lds_chunk_ctr = 0u; lds_done = 0u; lds_nblk[0] = lds_nblk[1] = 0u; }
   if (threadIdx.x < PT_POOL_BINS) lds_out[threadIdx.x] = (PT_POOL_NO_BLOCK << 12) | (uint32_t)PT_POOL_BLOCK; /* "full": the first push brings a block */
-  PtSceneView sv = pt_scene_view<MODE, LDS_SCENE, StackT>(sc, lds_raw, stack_depth); /* LDS_SCENE: ends with the workgroup's only barrier */
+  PtSceneView sv = pt_scene_view<MODE, LDS_SCENE, StackT>(sc, lds_raw, stack_depth); /* LDS_SCENE: ends with the workgroup's only barrier (SOLO: per bounce, two more) */
   if (!LDS_SCENE) {
     __shared__ double lds_floor[PT_FLOOR_LDS * 10];
     if (MODE == PT_MODE_ARRAY && sc.n_floor > 0) { /* the pre-tested floor triangles: see PtSceneView.floor_lds */
@@ -3001,6 +3054,12 @@ __global__ __launch_bounds__(PT_BOUNCE_THREADS, PT_BOUNCE_WAVES) void k_bounce(P
   uint32_t n_susp = 0; /* wave-uniform */
   bool more = true;    /* wave-uniform: the workgroup's share of the queue is not exhausted */
   unsigned long long c_nodes = 0, c_prims = 0, c_floor = 0, c_seg = 0, c_filter[2] = {0, 0}; /* COUNT: as in k_trace */
+  /* SOLO: the bounce this workgroup is at, its queues, and whether its input is the block list it noted in the bounce before */
+  uint32_t own_chunks = 0u, cur_list = 0u; /* own_blocks: chunks of lds_blk[cur_list]; pushes note into lds_blk[cur_list ^ 1] */
+  bool own_blocks = false;
+  uint32_t* const solo_cursor[2] = {out.count, out.count + 1}; /* the block cursors of the buffer written first / of the input's buffer */
+  uint32_t solo_turn = 0u;
+  if (SOLO && solo_on) hits.t += (size_t)(bounce & 1) * hits.t_parity_stride;
   /* PT_DIAG == 5 (tools/diag_phases.py; counting renders of diagnostic builds, queued rays' launches): where a wave's life goes,
    * in ticks of the 100 MHz clock summed over waves -- nodes = walks, prims = shade steps (with their pushes), floor = everything
    * else in the loop (chunk hand-out, ray loads, filing, parking), segments = the whole loop; undecided / fallback_steps = the
@@ -3009,6 +3068,7 @@ __global__ __launch_bounds__(PT_BOUNCE_THREADS, PT_BOUNCE_WAVES) void k_bounce(P
   unsigned long long tm_last = DIAG_T ? __builtin_readcyclecounter() : 0ull;
   const unsigned long long tm_begin = tm_last;
 #define PT_TM5(var) do { if (DIAG_T) { __builtin_amdgcn_sched_barrier(0); const unsigned long long now_ = __builtin_readcyclecounter(); (var) += now_ - tm_last; tm_last = now_; __builtin_amdgcn_sched_barrier(0); } } while (0)
+ for (;;) { /* (one turn per bounce; a launch that does not run solo leaves after the first) */
   for (;;) {
     PT_TM5(c_floor);
     const bool input_left = more || n_susp > 0;
@@ -3046,7 +3106,10 @@ __global__ __launch_bounds__(PT_BOUNCE_THREADS, PT_BOUNCE_WAVES) void k_bounce(P
       }
 #undef PT_POOL_STEP
       if (PT_DIAG == 7) PT_TM5(c_floor);
-      if (c != PT_CAT_MISS && !last_bounce) pt_pool_push<EMIT>(sc, out, so, lds_out);
+      if (c != PT_CAT_MISS && !last_bounce) {
+        if (SOLO && solo_on) pt_pool_push<EMIT>(sc, out, so, lds_out, lds_blk[SOLO ? (cur_list ^ 1u) : 0u], &lds_nblk[cur_list ^ 1u]);
+        else pt_pool_push<EMIT>(sc, out, so, lds_out);
+      }
       if (PT_DIAG == 6) PT_TM5(c_floor);
       else PT_TM5(c_prims);
       if (DIAG_T) c_filter[0] += (lane == 0);
@@ -3072,11 +3135,19 @@ __global__ __launch_bounds__(PT_BOUNCE_THREADS, PT_BOUNCE_WAVES) void k_bounce(P
       uint32_t unit = 0u;
       if (lane == 0) unit = __hip_atomic_fetch_add(&lds_chunk_ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       unit = (uint32_t)__builtin_amdgcn_readfirstlane((int)unit);
+      if (SOLO && own_blocks) { /* the workgroup's own blocks of the bounce before, PT_POOL_BLOCK / 64 chunks each (holes marked) */
+        more = unit < own_chunks;
+        if (more) {
+          i = lds_blk[SOLO ? cur_list : 0u][unit / (PT_POOL_BLOCK / PT_WAVE)] * (uint32_t)PT_POOL_BLOCK + (unit % (PT_POOL_BLOCK / PT_WAVE)) * PT_WAVE + (uint32_t)lane;
+          valid = true;
+        }
+      } else {
       unit = (unit / PT_POOL_RUN) * (n_wg * PT_POOL_RUN) + blockIdx.x * PT_POOL_RUN + (unit % PT_POOL_RUN);
       more = unit < total_chunks;
       if (more) {
         i = unit * PT_WAVE + (uint32_t)lane;
         valid = i < n;
+      }
       }
     }
     V3 o = v3(0.0, 0.0, 0.0), d = v3(0.0, 0.0, -1.0); /* P3.origin */
@@ -3155,6 +3226,41 @@ __global__ __launch_bounds__(PT_BOUNCE_THREADS, PT_BOUNCE_WAVES) void k_bounce(P
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
   }
+  if (!(SOLO && solo_on) || last_bounce) break;
+  /* SOLO: this workgroup's next bounce.  Every wave has filed, shaded and pushed its last ray of this one when the barrier
+   * opens; the unused tails of the part-filled blocks become holes, the blocks noted by the pushes become the input. */
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); /* the survivors' records, for the other waves of this workgroup */
+  __syncthreads();
+  for (int b = 0; b < PT_POOL_BINS; ++b) {
+    const uint32_t st = lds_out[b];
+    const uint32_t blk = st >> 12, pos = st & 0xfffu;
+    if (blk == PT_POOL_NO_BLOCK) continue;
+    for (uint32_t e = pos + threadIdx.x; e < (uint32_t)PT_POOL_BLOCK; e += blockDim.x)
+      out.ray[(size_t)blk * PT_POOL_BLOCK + e].dx = __hiloint2double((int)PT_HOLE_HI, 0);
+  }
+  own_chunks = lds_nblk[cur_list ^ 1u] * (uint32_t)(PT_POOL_BLOCK / PT_WAVE);
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); /* the holes */
+  __syncthreads(); /* everybody has read the bins and the list's length */
+  if (threadIdx.x == 0) {
+    lds_chunk_ctr = 0u;
+    lds_nblk[cur_list] = 0u;
+    /* the input's buffer is written from the second turn on: its cursor starts behind the launch's input (idempotent) */
+    if (solo_turn == 0u) atomicMax(solo_cursor[1], ((n + (uint32_t)PT_POOL_BLOCK - 1u) / (uint32_t)PT_POOL_BLOCK) * (uint32_t)PT_POOL_BLOCK);
+  }
+  if (threadIdx.x < PT_POOL_BINS) lds_out[threadIdx.x] = (PT_POOL_NO_BLOCK << 12) | (uint32_t)PT_POOL_BLOCK;
+  __syncthreads();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  if (own_chunks == 0u) break; /* (workgroup-uniform) none of this workgroup's paths is left */
+  cur_list ^= 1u;
+  own_blocks = true;
+  more = true;
+  ++bounce;
+  last_bounce = bounce == solo.max_bounces - 1;
+  { const PtQueue t_ = q; q = out; out = t_; }
+  ++solo_turn;
+  out.count = solo_cursor[solo_turn & 1u];
+  hits.t += (bounce & 1) ? (ptrdiff_t)hits.t_parity_stride : -(ptrdiff_t)hits.t_parity_stride;
+ }
   if (DIAG_T) {
     PT_TM5(c_floor);
     c_seg = (lane == 0) ? tm_last - tm_begin : 0ull;
@@ -3177,7 +3283,7 @@ __global__ __launch_bounds__(PT_BOUNCE_THREADS, PT_BOUNCE_WAVES) void k_bounce(P
       atomicAdd(&counters->fallback_steps, c_filter[1]);
     }
   }
-  if (last_bounce) return;
+  if (last_bounce || (SOLO && solo_on)) return; /* (a solo launch leaves no queue behind: its paths have all ended) */
   /* the workgroup's last wave marks what is left of its blocks as holes */
   uint32_t fin = 0u;
   if (lane == 0) fin = __hip_atomic_fetch_add(&lds_done, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);

@@ -57,7 +57,7 @@ def test_struct_layouts_match_c(tmp_path):
 def test_version_and_leaf_size():
     import path_tracer_ocaml_amd as P
     L = P.lib()
-    assert L.ptx_version() == 5  # 5: ptx_image_pin / ptx_image_unpin, ptx_render_params.flags validated (unknown bits are an error); 4: PTX_KERNEL_BOUNCE (ptx_stats.kernel_ms / kernel_launches have 6 entries); 3: ptx_stats.filter_* / peer_copies / staged_copies; 2: n_gpus, ptx_render_multi, ptx_scene_replicate, banded film
+    assert L.ptx_version() == 6  # 6: ptx_stats.solo_launches; 5: ptx_image_pin / ptx_image_unpin, ptx_render_params.flags validated (unknown bits are an error); 4: PTX_KERNEL_BOUNCE (ptx_stats.kernel_ms / kernel_launches have 6 entries); 3: ptx_stats.filter_* / peer_copies / staged_copies; 2: n_gpus, ptx_render_multi, ptx_scene_replicate, banded film
     from path_tracer_ocaml_amd import abi
     assert abi.PTX_ABI_VERSION == 4
     assert L.ptx_leaf_size() == 16  # LEAF_SIZE, sphere-intersect-rs/src/lib.rs:13

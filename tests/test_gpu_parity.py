@@ -422,6 +422,7 @@ def test_random_configs_raw_sums_bitwise(P, oracle, seed, monkeypatch):
     monkeypatch.setenv("PTX_BIN_KEY", str(int(rng.integers(0, 3))))  # survivors binned by octant / elevation / reaches-the-tree's-box
     monkeypatch.setenv("PTX_FUSED", str(int(rng.integers(0, 3))))  # k_bounce for every bounce / all but the camera rays' / k_trace + shade kernels
     monkeypatch.setenv("PTX_BOUNCE_THREADS", str(int(rng.choice([0, 64, 192, 512]))))  # k_bounce workgroup size (0 = 1024)
+    monkeypatch.setenv("PTX_SOLO_ENTRIES", str(int(rng.choice([0, 2000, 50000, 1 << 30]))))  # k_bounce: remaining bounces of a batch in one launch below this many entries
     monkeypatch.setenv("PTX_BOUNCE_FENCE_WG", str(int(rng.integers(0, 2))))  # k_bounce: wavefront- / workgroup-scope fences around a wave's own records
     monkeypatch.setenv("PTX_FUSED_GLOBAL", str(int(rng.integers(0, 2))))  # meshes walked from HBM / L2: k_bounce / k_trace + shade kernels
     monkeypatch.setenv("PTX_LDS_NODES64", str(int(rng.integers(0, 2))))  # LDS scenes: the undecided box tests' binary64 bounds from LDS / global memory
@@ -537,6 +538,42 @@ def test_bounce_kernel_on_a_mesh_walked_from_hbm(P, oracle, fused, threads, wgs,
             kl = st["kernel_launches"]
             assert kl["bounce"] == n_batches * (depth if fused == 2 else depth - 1), kl
             assert kl["trace"] == kl["shade"] == (0 if fused == 2 else n_batches), kl
+    g.close()
+
+
+@pytest.mark.parametrize("kind,entries,threads,wgs", [("shirley", 1 << 30, 0, 0), ("shirley", 60000, 0, 0), ("shirley", 1 << 30, 64, 6), ("shirley_no_simd", 1 << 30, 256, 0),
+                                                       ("cornell", 1 << 30, 0, 0), ("cornell", 100000, 128, 24), ("ganesha", 1 << 30, 0, 0), ("ganesha", 30000, 256, 9)])
+def test_solo_launch_runs_the_remaining_bounces(P, oracle, kind, entries, threads, wgs, monkeypatch):
+    """PTX_SOLO_ENTRIES: the first k_bounce launch of a batch whose input queue holds at most that many entries runs ALL remaining
+    bounces itself -- every workgroup reads back the blocks it wrote, bounce after bounce, workgroups drifting apart in bounce
+    number (the hit distances of even and odd bounces live in two halves of the array) -- and the later launches return at once.
+    Raw sums and work counters are the oracle's bit for bit, and ptx_stats.solo_launches shows one such launch per batch.  Small
+    workgroups / few of them: many chunks per wave per bounce, block lists of dozens of entries."""
+    torch = pytest.importorskip("torch")
+    monkeypatch.setenv("PTX_SOLO_ENTRIES", str(entries))
+    monkeypatch.setenv("PTX_BOUNCE_THREADS", str(threads))
+    monkeypatch.setenv("PTX_BOUNCE_WGS", str(wgs))
+    w, h, spp, depth = 384, 192, 6, 10
+    d = {"shirley": lambda: oracle.desc_shirley(w, h), "shirley_no_simd": lambda: oracle.desc_shirley(w, h, no_simd=True),
+         "cornell": lambda: oracle.desc_cornell(w, h), "ganesha": lambda: oracle.desc_ganesha_like(w, h, n_target=12000)}[kind]()
+    c = oracle.Scene(d.ptr, d).render(w, h, spp, depth, threads=8, want_raw=True, count=True)
+    g = P.Scene(d.ptr, 0, keepalive=d)
+    raw = torch.zeros((h, w, 3), dtype=torch.float64, device="cuda:0")
+    for streams in ("1", "2"):
+        monkeypatch.setenv("PTX_STREAMS", streams)
+        for count in (True, False):
+            raw.zero_()
+            st = g.render_raw_device(P.render_params(w, h, spp, depth, count_work=count, passes_per_batch=2), raw.data_ptr())
+            assert np.array_equal(bits(raw.cpu().numpy()), bits(c["raw"])), (streams, count)
+            if count:
+                for k in ("segments", "nodes_tested", "prims_tested", "floor_tested"):
+                    assert st[k] == c["counters"][k], k
+                n_batches = (spp + 1) // 2
+                if entries == 1 << 30:
+                    assert st["solo_launches"] == n_batches, st["solo_launches"]  # the first queued bounce of every batch
+                else:  # (a queue's length counts its holes, one part-filled block per workgroup and bin: it may never get that short)
+                    assert 0 <= st["solo_launches"] <= n_batches, st["solo_launches"]
+                    print(kind, entries, "solo launches", st["solo_launches"], "of", n_batches, "batches")
     g.close()
 
 
