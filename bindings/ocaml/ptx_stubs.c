@@ -35,31 +35,66 @@
 #include <caml/mlvalues.h>
 #include <caml/threads.h>
 
+#include <stdlib.h>
+
 #include "ptx_ml_marshal.h"
 
 typedef struct ptx_ml_handle {
   ptx_scene* scene;
-  int in_use; /* renders running on the scene right now (atomic: OCaml 5 domains run in parallel) */
+  /* renders running on the scene right now (atomic: OCaml 5 domains run in parallel); + PTX_ML_EXCLUSIVE while image_pin /
+   * image_unpin change what a render reads (the registered image): they need the scene to themselves */
+  int in_use;
+  /* the pinned image, kept alive from here: a generational global root in a malloc'ed cell (a custom block's own data may move
+   * with the block, a root's address may not), NULL while nothing is pinned.  While it exists the Bigarray cannot be collected,
+   * so neither a pin that outlives the caller's last reference nor the finaliser (whose order against the image's is not
+   * defined) can leave the library holding a registration of freed memory. */
+  value* pin_root;
 } ptx_ml_handle;
+#define PTX_ML_EXCLUSIVE (1 << 20)
 #define Handle_val(v) ((ptx_ml_handle*)Data_custom_val(v))
 #define Scene_val(v) (Handle_val(v)->scene)
 
-/* the finaliser: runs only when nothing reaches the handle any more, so no render can be using it */
+static void ptx_ml_drop_pin_root(ptx_ml_handle* h) {
+  if (h->pin_root) {
+    caml_remove_generational_global_root(h->pin_root);
+    free(h->pin_root);
+    h->pin_root = NULL;
+  }
+}
+/* the finaliser: runs only when nothing reaches the handle any more, so no render can be using it.  ptx_scene_destroy ends the
+ * pin (the image is still alive: the root below is dropped after it) */
 static void ptx_ml_scene_finalize(value v) {
   if (Scene_val(v)) {
     ptx_scene_destroy(Scene_val(v));
     Scene_val(v) = NULL;
   }
+  ptx_ml_drop_pin_root(Handle_val(v));
 }
-/* a render takes the scene for the time the runtime lock is released; NULL = already destroyed */
-static ptx_scene* ptx_ml_scene_acquire(value handle) {
+/* a render takes the scene for the time the runtime lock is released; NULL = already destroyed, or being re-pinned (*busy) */
+static ptx_scene* ptx_ml_scene_acquire(value handle, int* busy) {
   ptx_ml_handle* h = Handle_val(handle);
-  __atomic_add_fetch(&h->in_use, 1, __ATOMIC_ACQ_REL);
+  *busy = 0;
+  const int n = __atomic_add_fetch(&h->in_use, 1, __ATOMIC_ACQ_REL);
   ptx_scene* s = __atomic_load_n(&h->scene, __ATOMIC_ACQUIRE);
+  if (n >= PTX_ML_EXCLUSIVE) { /* image_pin / image_unpin is at work on another thread or domain */
+    *busy = 1;
+    s = NULL;
+  }
   if (!s) __atomic_sub_fetch(&h->in_use, 1, __ATOMIC_ACQ_REL);
   return s;
 }
 static void ptx_ml_scene_release(value handle) { __atomic_sub_fetch(&Handle_val(handle)->in_use, 1, __ATOMIC_ACQ_REL); }
+/* image_pin / image_unpin: the scene with NO render running, and none starting until ptx_ml_scene_release_exclusive.
+ * 1 = taken; 0 = a render (or another pin) is running: nothing changed */
+static int ptx_ml_scene_acquire_exclusive(value handle) {
+  ptx_ml_handle* h = Handle_val(handle);
+  if (__atomic_add_fetch(&h->in_use, PTX_ML_EXCLUSIVE, __ATOMIC_ACQ_REL) != PTX_ML_EXCLUSIVE) {
+    __atomic_sub_fetch(&h->in_use, PTX_ML_EXCLUSIVE, __ATOMIC_ACQ_REL);
+    return 0;
+  }
+  return 1;
+}
+static void ptx_ml_scene_release_exclusive(value handle) { __atomic_sub_fetch(&Handle_val(handle)->in_use, PTX_ML_EXCLUSIVE, __ATOMIC_ACQ_REL); }
 
 static struct custom_operations ptx_ml_scene_ops = {
     "dalev.path_tracer.ptx_scene", ptx_ml_scene_finalize, custom_compare_default, custom_hash_default,
@@ -138,6 +173,7 @@ CAMLprim value ptx_ml_scene_create_stub(value flat, value device) {
   handle = caml_alloc_custom(&ptx_ml_scene_ops, sizeof(ptx_ml_handle), 0, 1);
   Handle_val(handle)->scene = s;
   Handle_val(handle)->in_use = 0;
+  Handle_val(handle)->pin_root = NULL;
   CAMLreturn(handle);
 }
 
@@ -152,7 +188,8 @@ CAMLprim value ptx_ml_scene_destroy_stub(value handle) {
     __atomic_store_n(&h->scene, s, __ATOMIC_RELEASE); /* put it back: the finaliser or a later call frees it */
     caml_failwith("Ptx.scene_destroy: a render is running on this scene");
   }
-  ptx_scene_destroy(s);
+  ptx_scene_destroy(s); /* (ends a pin) */
+  ptx_ml_drop_pin_root(h);
   return Val_unit;
 }
 
@@ -172,17 +209,48 @@ CAMLprim value ptx_ml_scene_tree_stats_stub(value handle) {
   CAMLreturn(tuple);
 }
 
-/* external image_pin : scene -> image -> unit = "ptx_ml_image_pin_stub" / external image_unpin : scene -> unit (ptx_image_pin) */
+/* external image_pin : scene -> image -> unit = "ptx_ml_image_pin_stub" / external image_unpin : scene -> unit (ptx_image_pin).
+ * Both change the registration a running render reads (its last step is the DMA into the image): they take the scene
+ * exclusively and raise Failure while a render runs on another thread or domain; a render that starts meanwhile raises Failure
+ * too.  The pinned Bigarray is kept alive from the handle (ptx_ml_handle.pin_root). */
 CAMLprim value ptx_ml_image_pin_stub(value handle, value image) {
-  ptx_scene* s = Scene_val(handle);
+  CAMLparam2(handle, image);
+  if (!Scene_val(handle)) caml_invalid_argument("Ptx.image_pin: scene already destroyed");
+  if (!ptx_ml_scene_acquire_exclusive(handle)) caml_failwith("Ptx.image_pin: a render is running on this scene");
+  ptx_ml_handle* h = Handle_val(handle); /* (nothing below allocates on the OCaml heap: the block does not move) */
+  ptx_scene* s = __atomic_load_n(&h->scene, __ATOMIC_ACQUIRE);
+  int32_t rc = -1;
+  if (s) rc = ptx_image_pin(s, (double*)Caml_ba_data_val(image), (int64_t)Caml_ba_array_val(image)->dim[0]);
+  if (s && rc == 0) {
+    if (!h->pin_root) {
+      h->pin_root = (value*)malloc(sizeof(value));
+      if (h->pin_root) {
+        *h->pin_root = image;
+        caml_register_generational_global_root(h->pin_root);
+      } else { /* no cell for the root: do not keep a pin nothing keeps alive */
+        (void)ptx_image_unpin(s);
+        rc = -1;
+      }
+    } else {
+      caml_modify_generational_global_root(h->pin_root, image);
+    }
+  } else if (s) {
+    ptx_ml_drop_pin_root(h); /* ptx_image_pin ends the previous pin before it tries the new one */
+  }
+  ptx_ml_scene_release_exclusive(handle);
   if (!s) caml_invalid_argument("Ptx.image_pin: scene already destroyed");
-  if (ptx_image_pin(s, (double*)Caml_ba_data_val(image), (int64_t)Caml_ba_array_val(image)->dim[0]) != 0) caml_failwith(ptx_last_error());
-  return Val_unit;
+  if (rc != 0) caml_failwith(h->pin_root || rc != -1 ? ptx_last_error() : "Ptx.image_pin: out of memory");
+  CAMLreturn(Val_unit);
 }
 CAMLprim value ptx_ml_image_unpin_stub(value handle) {
-  ptx_scene* s = Scene_val(handle);
+  CAMLparam1(handle);
+  if (!ptx_ml_scene_acquire_exclusive(handle)) caml_failwith("Ptx.image_unpin: a render is running on this scene");
+  ptx_ml_handle* h = Handle_val(handle);
+  ptx_scene* s = __atomic_load_n(&h->scene, __ATOMIC_ACQUIRE);
   if (s) (void)ptx_image_unpin(s);
-  return Val_unit;
+  ptx_ml_drop_pin_root(h);
+  ptx_ml_scene_release_exclusive(handle);
+  CAMLreturn(Val_unit);
 }
 
 /* What a callback trampoline needs: the closure (a GC root registered by the stub that owns this struct) and the first
@@ -216,7 +284,9 @@ CAMLprim value ptx_ml_render_stub(value handle, value width, value height, value
   CAMLlocal1(exn);
   const intnat w = Long_val(width), h = Long_val(height);
   if (Caml_ba_array_val(image)->dim[0] != w * h * 3) caml_invalid_argument("Ptx.render: image must hold width * height * 3 floats");
-  ptx_scene* s = ptx_ml_scene_acquire(handle);
+  int busy = 0;
+  ptx_scene* s = ptx_ml_scene_acquire(handle, &busy);
+  if (!s && busy) caml_failwith("Ptx.render: the scene's image is being pinned or unpinned on another thread");
   if (!s) caml_invalid_argument("Ptx.render: scene already destroyed");
   double* out = (double*)Caml_ba_data_val(image); /* Bigarray data lives outside the OCaml heap: stable while the lock is released */
   const int32_t i_spp = (int32_t)Long_val(spp), i_mb = (int32_t)Long_val(max_bounces), i_gpus = (int32_t)Long_val(gpus);
@@ -283,7 +353,9 @@ CAMLprim value ptx_ml_ppm_render_stub(value handle, value params, value lights, 
   const intnat w = (intnat)p6[0], h = (intnat)p6[1];
   if (w <= 0 || h <= 0 || Caml_ba_array_val(img_sum)->dim[0] != w * h * 3)
     caml_invalid_argument("Ptx.ppm_render: img_sum must hold width * height * 3 floats");
-  ptx_scene* s = ptx_ml_scene_acquire(handle);
+  int busy = 0;
+  ptx_scene* s = ptx_ml_scene_acquire(handle, &busy);
+  if (!s && busy) caml_failwith("Ptx.ppm_render: the scene's image is being pinned or unpinned on another thread");
   if (!s) caml_invalid_argument("Ptx.ppm_render: scene already destroyed");
   exn = Val_unit;
   ptx_ml_ppm_cb cb = {{&on_iteration, &exn, 0}, (double*)Caml_ba_data_val(img_sum), (size_t)(w * h * 3)};

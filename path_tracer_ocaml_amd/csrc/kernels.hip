@@ -491,8 +491,8 @@ __device__ __forceinline__ uint32_t pt_stack_pop(const PtThreadOctTag*, int) { r
 
 /* One ray's traversal state.  begin() = Ray.create + the per-ray constants; node_step() = one visit of
  * Tree.intersect's recursion (shape_tree.ml:203-221); packet() = Leaf.intersect on the leaf the lane holds.
- * Two drivers use it: pt_trace_ray (one ray per lane, start to finish) and k_trace_stream (lanes are handed a new
- * ray as soon as enough of the wave has finished). */
+ * Driven by pt_trace_ray (one ray per lane; a chunk may stop early and its unfinished walks be resumed later, PtTailCtl) and by
+ * pt_trace_packet (camera rays of LDS-resident scenes). */
 template <int MODE, bool COUNT, bool ORIGIN_ZERO, typename StackT, bool SWZ>
 struct PtTraverser {
   /* the binary32 filter runs wherever the walk is threaded: on the LDS image (SWZ) and on the 32-byte global image */
@@ -860,83 +860,6 @@ struct PtTraverser {
     }
   }
 
-  /* ---- the same visit in two halves, for the walk from HBM / L2 with TWO rays per lane (pt_trace_ray2): the loads of
-   * both rays' nodes are issued before either is waited for, so a lane keeps two node -> child chains in flight. */
-  struct NodeWords {
-    uint4 w0, w1;
-    uint32_t skip;
-  };
-  __device__ __forceinline__ NodeWords load_node(const PtSceneView& sv, uint32_t nd) const {
-    static_assert(!SWZ, "the two-ray walk reads the 32-byte global image");
-    NodeWords w;
-    if (nd & PT_TOP_FLAG) {
-      const unsigned char* b = sv.top + (nd & (PT_TOP_FLAG - 1u));
-      w.w0 = ((const uint4*)b)[0];
-      w.w1 = ((const uint4*)b)[1];
-      const uint32_t s16 = (uint32_t)*(const uint16_t*)(b + 32u + 2u * dirs);
-      w.skip = s16 == 0xffffu ? 0xffffffffu : (PT_TOP_FLAG | s16);
-    } else {
-      const uint4* p = (const uint4*)(sv.nodes32 + (size_t)nd * 32u);
-      w.w0 = p[0];
-      w.w1 = p[1];
-      w.skip = sv.skip32[(size_t)nd * 8u + dirs];
-    }
-    return w;
-  }
-  /* node_step's arithmetic on words that have arrived (G32 branch of test_box + the descend / leaf / skip decision) */
-  __device__ __forceinline__ void finish_node(const PtSceneView& sv, const NodeWords& w, unsigned long long& c_nodes,
-                                              unsigned long long& c_prims) {
-    if (COUNT) c_nodes++;
-    const uint4 w0 = w.w0, w1 = w.w1;
-    const uint32_t na = w1.z;
-    const bool leaf = (w1.w >> 30) == PT_NODE_LEAF_AXIS;
-    const uint32_t n_real = (w1.w >> 15) & 0x7fffu;
-    const uint32_t nb = leaf ? ((w1.w & 0x7fffu) | (PT_NODE_LEAF_AXIS << 30)) : w1.w;
-    const float mag = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(__uint_as_float(w0.x)), __builtin_fabsf(__uint_as_float(w0.y))),
-                                                      __builtin_fmaxf(__builtin_fabsf(__uint_as_float(w0.z)), __builtin_fabsf(__uint_as_float(w0.w)))),
-                                      __builtin_fmaxf(__builtin_fabsf(__uint_as_float(w1.x)), __builtin_fabsf(__uint_as_float(w1.y)))) * 1.000001f;
-    const float t0x = __builtin_fmaf(__uint_as_float(w0.x), fix, fnx), t1x = __builtin_fmaf(__uint_as_float(w0.w), fix, fnx);
-    const float t0y = __builtin_fmaf(__uint_as_float(w0.y), fiy, fny), t1y = __builtin_fmaf(__uint_as_float(w1.x), fiy, fny);
-    const float t0z = __builtin_fmaf(__uint_as_float(w0.z), fiz, fnz), t1z = __builtin_fmaf(__uint_as_float(w1.y), fiz, fnz);
-    const float a = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(t0x, t1x), __builtin_fminf(t0y, t1y)), __builtin_fminf(t0z, t1z));
-    const float b = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(t0x, t1x), __builtin_fmaxf(t0y, t1y)), __builtin_fmaxf(t0z, t1z));
-    const float u = __builtin_fminf(b, t32) - __builtin_fmaxf(a, 0.0f);
-    const float m2 = __builtin_fmaf(mag, k2, c2);
-    bool hit = u >= m2;
-    const bool undecided = !(__builtin_fabsf(u) >= m2); /* as in test_box; exact_slab rays carry m2 = NaN */
-    if (__builtin_amdgcn_ballot_w64(undecided) != 0) {
-      if (COUNT) {
-        if (undecided) n_undecided++;
-        if (pt_lane() == __ffsll((long long)__ballot(1)) - 1) n_wave_fallbacks++;
-      }
-      if (undecided) { /* the reference's arithmetic on the binary64 node, as in test_box */
-        const PtNode* np = sv.nodes + ((node & PT_TOP_FLAG) ? *(const uint32_t*)(sv.top + (node & (PT_TOP_FLAG - 1u)) + 48) : node);
-        double qx = d.x, qy = d.y, qz = d.z;
-        asm volatile("" : "+v"(qx), "+v"(qy), "+v"(qz));
-        const V3 inv64 = v3(1.0 / qx, 1.0 / qy, 1.0 / qz);
-        hit = (!(pt_isfinite(inv64.x) && pt_isfinite(inv64.y) && pt_isfinite(inv64.z)))
-                  ? pt_slab_hit_exact(np->mn, o, inv64, 0.0, r.t)
-                  : pt_slab_hit_fast<ORIGIN_ZERO>(np->mn, o, inv64, 0.0, r.t);
-      }
-    }
-    bool descend = false;
-    if (hit) {
-      if (leaf) {
-        leaf_first = (int)na;
-        leaf_n = (int)n_real;
-        if (COUNT) c_prims += (unsigned long long)(nb & 0x3fffffffu);
-      } else {
-        const uint32_t axis = nb >> 30;
-        node = ((dirs >> axis) & 1u) ? na : (nb & 0x3fffffffu); /* near child first (shape_tree.ml:209) */
-        descend = true;
-      }
-    }
-    if (!descend) {
-      if (w.skip == 0xffffffffu) walking = false;
-      else node = w.skip;
-    }
-  }
-
   /* Leaf.intersect on the held leaf (caller checks leaf_n > 0) */
   __device__ __forceinline__ void packet(const PtSceneView& sv, unsigned long long& c_nodes, unsigned long long& c_floor) {
     const double t_min = 0.0;
@@ -1183,70 +1106,6 @@ __device__ __forceinline__ PtTraceResult pt_trace_ray(const PtSceneDev& sc, cons
     c_filter[1] += tr.n_wave_fallbacks;
   }
   return tr.r;
-}
-
-/* Scene.intersect for TWO rays held by this lane (A and B), walked from HBM / L2 over the threaded 32-byte image.
- * Large scenes (ganesha-like: 92 k nodes) walk from L2 / Infinity Cache and wait for the chain node -> child: with one ray
- * per lane a wave spent 64 % of its life parked on s_waitcnt with the vector pipe half busy (profiles/r02_ganesha_sq.json),
- * and more waves per SIMD are not to be had (the triangle test needs ~100 VGPRs).  Two rays per lane double the chains in
- * flight at the same occupancy: both rays' node words are requested before either is tested.  Each ray still performs exactly
- * pt_trace_ray's own sequence of box and leaf tests (its state is its own traverser), so hits, t and the work counters are
- * unchanged.  Leaves are tested one ray at a time (the triangle code is what the registers are sized for).
- * Tail cut as in pt_trace_ray: the pair of chunks stops once fewer than `min_active` of its <= 128 rays are still walking. */
-#ifndef PT_DUAL_WALK_MIN
-#define PT_DUAL_WALK_MIN 12
-#endif
-template <int MODE, bool COUNT, bool ORIGIN_ZERO>
-__device__ __forceinline__ void pt_trace_ray2(const PtSceneDev& sc, const PtSceneView& sv, V3 oA, V3 dA, V3 oB, V3 dB, bool validA,
-                                              bool validB, PtTailCtl& tcA, PtTailCtl& tcB, int min_active, PtTraceResult& rA,
-                                              PtTraceResult& rB, unsigned long long& c_nodes, unsigned long long& c_prims,
-                                              unsigned long long& c_floor, unsigned long long* c_filter) {
-  typedef PtTraverser<MODE, COUNT, ORIGIN_ZERO, PtThreadTag, false> Tr;
-  Tr A, B;
-  unsigned long long no_count = 0;
-  A.begin(sc, sv, oA, dA, (validA && !tcA.resume) ? c_floor : no_count);
-  B.begin(sc, sv, oB, dB, (validB && !tcB.resume) ? c_floor : no_count);
-  if (tcA.resume) {
-    A.node = tcA.node; A.r.t = tcA.t; A.r.u = tcA.u; A.r.v = tcA.v; A.r.slot = tcA.slot;
-    A.update_t32();
-  }
-  if (tcB.resume) {
-    B.node = tcB.node; B.r.t = tcB.t; B.r.u = tcB.u; B.r.v = tcB.v; B.r.slot = tcB.slot;
-    B.update_t32();
-  }
-  if (!validA) A.park();
-  if (!validB) B.park();
-  for (;;) {
-    if (__ballot(A.walking || A.leaf_n > 0 || B.walking || B.leaf_n > 0) == 0) break;
-    for (;;) {
-      const bool wantA = A.wants_node(), wantB = B.wants_node();
-      const unsigned long long wa = __ballot(wantA), wb = __ballot(wantB);
-      if ((wa | wb) == 0) break;
-      if ((int)(__popcll(wa) + __popcll(wb)) < PT_DUAL_WALK_MIN && __ballot(A.leaf_n > 0 || B.leaf_n > 0) != 0) break;
-      /* both requests go out before either answer is looked at; only the lanes that want a step ask (the texture-address
-       * unit works per active lane: unconditional loads for all 64 lanes more than doubled its load at 0.4 lane utilisation) */
-      typename Tr::NodeWords wA, wB;
-      wA.w0 = wA.w1 = wB.w0 = wB.w1 = make_uint4(0, 0, 0, 0);
-      wA.skip = wB.skip = 0u;
-      if (wantA) wA = A.load_node(sv, A.node);
-      if (wantB) wB = B.load_node(sv, B.node);
-      if (wantA) A.finish_node(sv, wA, c_nodes, c_prims);
-      if (wantB) B.finish_node(sv, wB, c_nodes, c_prims);
-    }
-    if (A.leaf_n > 0) A.packet(sv, c_nodes, c_floor);
-    if (B.leaf_n > 0) B.packet(sv, c_nodes, c_floor);
-    if (min_active > 0 && (int)(__popcll(__ballot(A.walking)) + __popcll(__ballot(B.walking))) < min_active) break;
-  }
-  tcA.unfinished = validA && A.walking;
-  tcA.node = A.node;
-  tcB.unfinished = validB && B.walking;
-  tcB.node = B.node;
-  if (COUNT && c_filter) {
-    c_filter[0] += A.n_undecided + B.n_undecided;
-    c_filter[1] += A.n_wave_fallbacks + B.n_wave_fallbacks;
-  }
-  rA = A.r;
-  rB = B.r;
 }
 
 /* Camera rays: the 64 rays of a wave are one 8x8 pixel tile of one pass, so they walk the tree TOGETHER -- one
@@ -1508,9 +1367,6 @@ __device__ __forceinline__ PtSceneView pt_scene_view(const PtSceneDev& sc, unsig
 #ifndef PT_DYNAMIC_CHUNKS
 #define PT_DYNAMIC_CHUNKS 2
 #endif
-#ifndef PT_DYNAMIC_WINDOWS
-#define PT_DYNAMIC_WINDOWS 1
-#endif
 /* PT_DYNAMIC_CHUNKS: 0 = static stride per wave; 1 = global counters (above); 2 = the workgroup keeps its static
  * share (chunks blockIdx, blockIdx + gridDim, ...) and its waves take them from a counter in LDS: no global atomic,
  * and a workgroup's total is the sum of ~450 chunk costs instead of a wave's ~28, so the spread between workgroups is
@@ -1594,10 +1450,6 @@ struct PtChunkFeed {
 #ifndef PT_TRACE_DIV_LOOP
 #define PT_TRACE_DIV_LOOP(LDS_SCENE) (PT_WALK_LOOP != 0 || !(LDS_SCENE))
 #endif
-#ifndef PT_TRACE_DUAL
-#define PT_TRACE_DUAL 0 /* scenes walked from HBM / L2: 1 = two rays per lane (pt_trace_ray2), 0 = one */
-#endif
-#define PT_DUAL_SUSP_CAP 128 /* parked walks a wave of the two-ray kernel can hold */
 #ifndef PT_TRACE_BLOCK_LDS
 #define PT_TRACE_BLOCK_LDS 1024 /* workgroup size when the scene is copied to LDS (one copy per workgroup) */
 #endif
@@ -1674,102 +1526,6 @@ __global__ __launch_bounds__(PT_TRACE_BLOCK_OF(MODE, LDS_SCENE), (LDS_SCENE && M
       const PtTraceResult r = pt_trace_packet<MODE, COUNT, PRIMARY, LDS_SCENE>(sc, sv, wstack, valid, o, d, c_nodes, c_prims, c_floor, c_filter);
       if (valid) {
         pt_hit_store(hits, i, r.t, r.slot, r.u, r.v, MODE == PT_MODE_ARRAY && sc.has_triangles);
-      }
-    }
-  } else if constexpr (!LDS_SCENE && PT_TRACE_DUAL != 0 && PT_DIAG == 0) {
-    /* TWO rays per lane (pt_trace_ray2): the wave takes two chunks at a time -- fresh ones from the feed, or 64 parked
-     * walks from its own list.  Tail cut on the pair: it stops once fewer than 2 x PT_TAIL_CUT of its <= 128 rays are
-     * still walking; at most 2 x PT_TAIL_CUT - 1 states are parked per turn, 64 are taken back as soon as 64 have gathered,
-     * so the list never holds more than 63 + 31 (PT_DUAL_SUSP_CAP = 128 per wave, three 16-byte words per state). */
-    constexpr bool TAIL_UV = MODE == PT_MODE_ARRAY;
-    uint4* my_susp = susp + ((size_t)blockIdx.x * (blockDim.x >> 6) + wave_in_block) * (PT_DUAL_SUSP_CAP * 3);
-    uint32_t n_susp = 0; /* wave-uniform */
-    bool more = true;
-    for (;;) {
-      bool got[2], resume[2], valid[2];
-      uint32_t idx[2];
-      uint4 parked[2], parked_uv[2], parked_w[2];
-#pragma unroll
-      for (int k = 0; k < 2; ++k) {
-        got[k] = resume[k] = valid[k] = false;
-        idx[k] = 0;
-        parked[k] = parked_uv[k] = parked_w[k] = make_uint4(0, 0, 0, 0);
-        if (n_susp >= (uint32_t)PT_WAVE || (!more && n_susp > 0)) {
-          const uint32_t take = n_susp < (uint32_t)PT_WAVE ? n_susp : (uint32_t)PT_WAVE, base = n_susp - take;
-          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); /* this wave's own parked states, written below */
-          got[k] = resume[k] = true;
-          valid[k] = (uint32_t)lane < take;
-          if (valid[k]) {
-            parked[k] = my_susp[base + lane];
-            parked_w[k] = my_susp[2 * PT_DUAL_SUSP_CAP + base + lane];
-            if (TAIL_UV) parked_uv[k] = my_susp[PT_DUAL_SUSP_CAP + base + lane];
-          }
-          idx[k] = parked[k].x;
-          n_susp = base;
-        } else if (more) {
-          more = feed.take(chunk);
-          if (more) {
-            got[k] = true;
-            idx[k] = chunk * PT_WAVE + lane;
-            valid[k] = idx[k] < n;
-          }
-        }
-      }
-      if (!got[0] && !got[1]) break;
-      V3 o[2], d[2];
-      PtTailCtl tc[2];
-#pragma unroll
-      for (int k = 0; k < 2; ++k) {
-        o[k] = v3(0.0, 0.0, 0.0);
-        d[k] = v3(0.0, 0.0, -1.0); /* P3.origin */
-        if (valid[k]) {
-          if (PRIMARY) {
-            const PtPrimarySample ps = pt_primary_decode(g, idx[k]);
-            valid[k] = ps.valid;
-            if (valid[k]) d[k] = pt_primary_dir(sc, g, ps, alpha);
-          } else {
-            pt_q_load_ray(q, idx[k], o[k], d[k]);
-            if (pt_is_hole(d[k].x)) { /* never parked, so never seen on resume */
-              valid[k] = false;
-              hits.slot[idx[k]] = PT_SLOT_HOLE;
-              o[k] = v3(0.0, 0.0, 0.0);
-              d[k] = v3(0.0, 0.0, -1.0);
-            }
-          }
-        }
-        if (COUNT && valid[k] && !resume[k]) c_seg++;
-        tc[k].min_active = 0;
-        tc[k].resume = resume[k] && valid[k];
-        tc[k].node = parked_w[k].x;
-        tc[k].slot = (int)parked_w[k].y;
-        tc[k].t = __hiloint2double((int)parked[k].w, (int)parked[k].z);
-        tc[k].u = __hiloint2double((int)parked_uv[k].y, (int)parked_uv[k].x);
-        tc[k].v = __hiloint2double((int)parked_uv[k].w, (int)parked_uv[k].z);
-        tc[k].unfinished = false;
-      }
-      PtTraceResult r[2];
-      /* the last chunks of a wave run to completion */
-      pt_trace_ray2<MODE, COUNT, PRIMARY>(sc, sv, o[0], d[0], o[1], d[1], valid[0], valid[1], tc[0], tc[1], more ? 2 * PT_TAIL_CUT : 0, r[0],
-                                          r[1], c_nodes, c_prims, c_floor, c_filter);
-#pragma unroll
-      for (int k = 0; k < 2; ++k) {
-        const bool park = tc[k].unfinished;
-        if (valid[k] && !park) {
-          pt_hit_store(hits, idx[k], r[k].t, r[k].slot, r[k].u, r[k].v, MODE == PT_MODE_ARRAY && sc.has_triangles);
-        }
-        const unsigned long long pm = __ballot(park);
-        if (pm != 0) {
-          if (park) {
-            const uint32_t at = n_susp + (uint32_t)__popcll(pm & ((1ull << lane) - 1ull));
-            my_susp[at] = make_uint4(idx[k], 0u, (uint32_t)__double2loint(r[k].t), (uint32_t)__double2hiint(r[k].t));
-            my_susp[2 * PT_DUAL_SUSP_CAP + at] = make_uint4(tc[k].node, (uint32_t)r[k].slot, 0u, 0u);
-            if (TAIL_UV)
-              my_susp[PT_DUAL_SUSP_CAP + at] = make_uint4((uint32_t)__double2loint(r[k].u), (uint32_t)__double2hiint(r[k].u),
-                                                          (uint32_t)__double2loint(r[k].v), (uint32_t)__double2hiint(r[k].v));
-          }
-          n_susp += (uint32_t)__popcll(pm);
-          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        }
       }
     }
   } else {
@@ -1879,107 +1635,6 @@ __global__ __launch_bounds__(PT_TRACE_BLOCK_OF(MODE, LDS_SCENE), (LDS_SCENE && M
       atomicAdd(&counters->segments, c_seg);
       atomicAdd(&counters->undecided, c_filter[0]);
       atomicAdd(&counters->fallback_steps, c_filter[1]);
-    }
-  }
-}
-
-/* The same stage for queued (bounce >= 1) rays as a STREAM: a lane whose ray has finished does not wait for the
- * slowest ray of its group of 64 -- once PT_REFILL_MIN lanes are idle they hand in their results and take the next
- * rays of the wave's share of the queue.  On a large mesh most bounce rays leave for the sky after 1-3 node tests
- * while a few walk 100+ nodes: with fixed groups of 64 the node walk ran at 23 % lane utilisation (ganesha-like,
- * tools/diag_utilisation.sh), nearly all of it lanes waiting for the group's longest ray.
- * The wave owns queue chunks gwave, gwave + nwaves, ... of 64 rays and numbers their entries 0, 1, 2, ... in that
- * order ("positions"); idle lanes take consecutive positions, so refill reads stay coalesced and no atomics are
- * needed.  Every ray still runs exactly pt_trace_ray's sequence of node and packet tests. */
-#ifndef PT_REFILL_MIN
-#define PT_REFILL_MIN 24
-#endif
-#ifndef PT_STREAM_WALK_MIN
-#define PT_STREAM_WALK_MIN 16
-#endif
-template <int MODE, bool COUNT, bool LDS_SCENE>
-__global__ __launch_bounds__(PT_TRACE_BLOCK_OF(MODE, LDS_SCENE), PT_TRACE_GLOBAL_WAVES) void k_trace_stream(
-    PtSceneDev sc, PtQueue q, PtHits hits, int stack_depth, PtCounters* counters) {
-  extern __shared__ __attribute__((aligned(64))) unsigned char lds_raw[];
-  const int lane = pt_lane();
-  const int wave_in_block = (int)(threadIdx.x >> 6);
-  const uint32_t waves_per_block = blockDim.x >> 6;
-  typedef typename std::conditional<LDS_SCENE, uint16_t, PtThreadTag>::type StackT; /* no per-lane stack anywhere: both walks are threaded */
-  StackT* stack = (StackT*)(lds_raw + (size_t)wave_in_block * PT_WAVE_STACK_BYTES(LDS_SCENE, StackT, stack_depth));
-  const PtSceneView sv = pt_scene_view<MODE, LDS_SCENE, StackT>(sc, lds_raw, stack_depth);
-  const uint32_t n = *q.count;
-  const uint32_t gwave = blockIdx.x * waves_per_block + wave_in_block;
-  const uint32_t nwaves = gridDim.x * waves_per_block;
-  const uint32_t total_chunks = (n + PT_WAVE - 1) / PT_WAVE;
-  const uint32_t my_positions = gwave < total_chunks ? ((total_chunks - gwave + nwaves - 1) / nwaves) * PT_WAVE : 0u;
-  unsigned long long c_nodes = 0, c_prims = 0, c_floor = 0, c_seg = 0;
-
-  PtTraverser<MODE, COUNT, false, StackT, LDS_SCENE> tr;
-  tr.park();
-  tr.r.t = 0.0;
-  tr.r.u = 0.0;
-  tr.r.v = 0.0;
-  tr.r.slot = -1;
-  uint32_t ray = 0xffffffffu; /* queue index of the ray this lane holds */
-  uint32_t pos = 0;           /* wave-uniform: next position nobody holds yet */
-  for (;;) {
-    const bool idle = tr.idle();
-    const unsigned long long im = __ballot(idle);
-    const bool more = pos < my_positions;
-    if (im == ~0ull || (more && (int)__popcll(im) >= PT_REFILL_MIN)) {
-      /* hand in the finished rays, take the next positions */
-      if (idle && ray != 0xffffffffu) {
-        pt_hit_store(hits, ray, tr.r.t, tr.r.slot, tr.r.u, tr.r.v, MODE == PT_MODE_ARRAY && sc.has_triangles);
-        ray = 0xffffffffu;
-      }
-      if (!more) break; /* every lane idle and nothing left */
-      if (idle) {
-        const uint32_t p = pos + (uint32_t)__popcll(im & ((1ull << lane) - 1ull));
-        const uint32_t i = (gwave + (p >> 6) * nwaves) * PT_WAVE + (p & 63u);
-        if (p < my_positions && i < n) {
-          ray = i;
-          if (COUNT) c_seg++;
-          V3 ro, rd;
-          pt_q_load_ray(q, i, ro, rd);
-          if (pt_is_hole(rd.x)) { /* an unused entry of a blocked queue (k_shade_pool): recorded and dropped, the lane stays idle */
-            hits.slot[i] = PT_SLOT_HOLE;
-            ray = 0xffffffffu;
-            if (COUNT) c_seg--;
-          } else {
-            tr.begin(sc, sv, ro, rd, c_floor);
-          }
-        }
-      }
-      pos += (uint32_t)__popcll(im);
-      continue;
-    }
-    for (;;) {
-      const bool want = tr.wants_node();
-      const unsigned long long wm = __ballot(want);
-      if (wm == 0) break;
-      if ((int)__popcll(wm) < PT_STREAM_WALK_MIN && __ballot(tr.leaf_n > 0) != 0) break;
-      if (more && (int)__popcll(__ballot(tr.idle())) >= PT_REFILL_MIN) break;
-      if (COUNT && PT_DIAG == 1) PT_DIAG_WAVE_SLOTS(c_floor);
-      if (!want) continue;
-      tr.node_step(sv, stack, c_nodes, c_prims);
-    }
-    /* also when the walk stopped for a refill: the lanes that hold a leaf test it now and walk on together with the
-     * newcomers (making them wait for the newcomers' first leaf cost more walk utilisation than it saved here) */
-    if (tr.leaf_n > 0) tr.packet(sv, c_nodes, c_floor);
-  }
-  if (COUNT) {
-    c_nodes = pt_wave_sum(c_nodes);
-    c_prims = pt_wave_sum(c_prims);
-    c_floor = pt_wave_sum(c_floor);
-    c_seg = pt_wave_sum(c_seg);
-    const unsigned long long c_und = pt_wave_sum(tr.n_undecided), c_fb = pt_wave_sum(tr.n_wave_fallbacks);
-    if (lane == 0) {
-      atomicAdd(&counters->nodes, c_nodes);
-      atomicAdd(&counters->prims, c_prims);
-      atomicAdd(&counters->floor, c_floor);
-      atomicAdd(&counters->segments, c_seg);
-      atomicAdd(&counters->undecided, c_und);
-      atomicAdd(&counters->fallback_steps, c_fb);
     }
   }
 }
@@ -2233,38 +1888,6 @@ struct PtContrib {
   double4* rgbx;
 };
 
-/* block-aggregated append: ONE atomic per workgroup iteration instead of one per wave (a single
- * counter word sustains only ~88 atomics/us chip-wide -- MI355X_MICROARCH.md "dequeue" -- which capped a
- * per-wave scheme at ~5.6 G paths/s).  lds: blockDim/64 + 1 words.  Must be called by every thread. */
-__device__ __forceinline__ uint32_t pt_block_append(uint32_t* counter, bool keep, uint32_t* lds) {
-  const unsigned long long mask = __ballot(keep);
-  const int lane = pt_lane();
-  const int wave = (int)(threadIdx.x >> 6), nw = (int)(blockDim.x >> 6);
-  const uint32_t rank = (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
-  if (lane == 0) lds[wave] = (uint32_t)__popcll(mask);
-  __syncthreads();
-  uint32_t before = 0, total = 0;
-  for (int w = 0; w < nw; ++w) {
-    const uint32_t c = lds[w];
-    before += (w < wave) ? c : 0u;
-    total += c;
-  }
-  if (threadIdx.x == 0) lds[nw] = total ? atomicAdd(counter, total) : 0u;
-  __syncthreads();
-  const uint32_t base = lds[nw];
-  __syncthreads();
-  return base + before + rank;
-}
-
-
-#ifndef PT_APPEND_BINS
-#define PT_APPEND_BINS 8
-#endif
-/* block-aggregated append that also BINS the survivors of this workgroup iteration by `key` (the direction
- * octant of the new ray): inside the workgroup's slice of the output queue, rays of one octant are contiguous,
- * so the waves of the next trace launch walk the tree in the same child order.  One atomic per iteration.
- * lds: PT_APPEND_BINS * (blockDim/64) + 1 words (<= 65). */
-static_assert(PT_APPEND_BINS == 1 || PT_APPEND_BINS == 8, "the bin key has 8 values");
 /* The bin a survivor is appended under.  Scenes whose primitives lie in a slab (Shirley: spheres on a ground plane;
  * PtSceneDev.sort_by_elevation, decided at scene creation): the ELEVATION of the new direction above that plane in 8 steps --
  * a predictor of the LENGTH of the next walk: rays that climb leave the slab after a few node tests, grazing rays cross the
@@ -2292,80 +1915,6 @@ __device__ __forceinline__ int pt_bin_key(const PtSceneDev& sc, V3 o, V3 d) {
   }
   return (d.x >= 0.0 ? 1 : 0) | (d.y >= 0.0 ? 2 : 0) | (d.z >= 0.0 ? 4 : 0);
 }
-template <bool TRAILING_SYNC>
-__device__ __forceinline__ uint32_t pt_block_append_binned(uint32_t* counter, bool keep, int key, uint32_t* lds, unsigned long long* tm_first_barrier = nullptr) {
-  const int lane = pt_lane();
-  const int wave = (int)(threadIdx.x >> 6), nw = (int)(blockDim.x >> 6);
-  uint32_t rank = 0;
-#pragma unroll
-  for (int k = 0; k < PT_APPEND_BINS; ++k) {
-    const unsigned long long m = __ballot(keep && key == k);
-    if (key == k) rank = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-    if (lane == 0) lds[k * nw + wave] = (uint32_t)__popcll(m);
-  }
-  const unsigned long long tm0 = tm_first_barrier ? __builtin_readcyclecounter() : 0ull;
-  __syncthreads();
-  if (tm_first_barrier) *tm_first_barrier += __builtin_readcyclecounter() - tm0; /* diagnostic builds: waiting for the window's slowest wave */
-  if (wave == 0) {
-    const int entries = PT_APPEND_BINS * nw; /* <= 64 */
-    const uint32_t v = lane < entries ? lds[lane] : 0u;
-    uint32_t incl = v;
-    for (int off = 1; off < 64; off <<= 1) {
-      const uint32_t up = (uint32_t)__shfl_up((int)incl, off, 64);
-      if (lane >= off) incl += up;
-    }
-    const uint32_t total = (uint32_t)__shfl((int)incl, 63, 64);
-    uint32_t base = 0;
-    if (lane == 0 && total) base = atomicAdd(counter, total);
-    base = (uint32_t)__shfl((int)base, 0, 64);
-    if (lane < entries) lds[lane] = base + incl - v;
-  }
-  __syncthreads();
-  const uint32_t dst = lds[key * nw + wave] + rank;
-  /* protects `lds` against the NEXT call; not needed when other workgroup barriers separate the calls anyway */
-  if (TRAILING_SYNC) __syncthreads();
-  return dst;
-}
-
-/* The body of `loop` in Integrator.path_tracer (integrator.ml:30-66) for one segment of every live path:
- * consumes (ray, hit), writes either the path's final colour or the next ray into `out`.
- * PRIMARY: bounce 0 -- the ray, attn0 = white and emit0 = black are recomputed, not read. */
-#ifndef PT_SHADE_SORT
-#define PT_SHADE_SORT 1
-#endif
-
-/* Workgroup-local counting sort of the next blockDim entries by shading category (miss / Lambertian solid /
- * Lambertian checker / metal / dielectric): after it, thread t handles entry perm[t] and every wave executes
- * (almost) one category.  Unsorted, a secondary wave holds all of them at once and runs the sum of their code
- * paths with ~40 % of its lanes active.  lds_cnt: PT_N_CAT * (blockDim/64) words; perm: blockDim u16. */
-__device__ __forceinline__ uint32_t pt_block_sort_by_category(int key, uint32_t* lds_cnt, uint16_t* perm) {
-  const int lane = pt_lane();
-  const int wave = (int)(threadIdx.x >> 6), nw = (int)(blockDim.x >> 6);
-  uint32_t rank = 0;
-#pragma unroll
-  for (int k = 0; k < PT_N_CAT; ++k) {
-    const unsigned long long m = __ballot(key == k);
-    if (key == k) rank = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-    if (lane == 0) lds_cnt[k * nw + wave] = (uint32_t)__popcll(m);
-  }
-  __syncthreads();
-  if (wave == 0) { /* exclusive prefix over the (category-major, wave-minor) table: <= 64 entries */
-    const int entries = PT_N_CAT * nw;
-    uint32_t v = lane < entries ? lds_cnt[lane] : 0u;
-    uint32_t incl = v;
-    for (int off = 1; off < 64; off <<= 1) {
-      const uint32_t up = (uint32_t)__shfl_up((int)incl, off, 64);
-      if (lane >= off) incl += up;
-    }
-    if (lane < entries) lds_cnt[lane] = incl - v;
-  }
-  __syncthreads();
-  const uint32_t pos = lds_cnt[key * nw + wave] + rank;
-  perm[pos] = (uint16_t)threadIdx.x;
-  __syncthreads();
-  return (uint32_t)perm[threadIdx.x];
-}
-
 /* What one segment leaves behind: either the path's final colour (written to `contrib` inside) or the next ray. */
 struct PtShadeOut {
   bool keep;
@@ -2508,154 +2057,18 @@ __device__ __forceinline__ void pt_shade_entry(const PtSceneDev& sc, const PtQue
     so.offset = offset;
 }
 
-#ifndef PT_SHADE_BLOCK
-#define PT_SHADE_BLOCK 512 /* <= 512: the category / bin tables are scanned by one wave (<= 64 entries) */
-#endif
-#ifndef PT_SHADE_PREFETCH
-#define PT_SHADE_PREFETCH 1
-#endif
 #ifndef PT_SHADE_WAVES
 #define PT_SHADE_WAVES 4
 #endif
 #ifndef PT_SHADE_TIMING
 #define PT_SHADE_TIMING 0
 #endif
-template <bool EMIT, bool PRIMARY>
-__global__ __launch_bounds__(PT_SHADE_BLOCK, PT_SHADE_WAVES) void k_shade(PtSceneDev sc, PtQueue q, PtHits hits, PtQueue out, PtContrib contrib,
-                                                const double* __restrict__ alpha, int bounce, int last_bounce,
-                                                PtGenParams g, uint32_t n_primary, uint32_t* work) {
-#if PT_APPEND_BINS > 1
-  __shared__ uint32_t lds_bins[65];
-#else
-  __shared__ uint32_t lds_append[17];
-#endif
-  __shared__ uint32_t lds_cnt[PT_N_CAT * 8];
-  __shared__ uint16_t lds_perm[PT_SHADE_BLOCK];
-  __shared__ uint32_t lds_win[2];
-  const uint32_t n = PRIMARY ? n_primary : *q.count;
-
-  /* Windows of blockDim entries are handed out dynamically (PtChunkFeed's counters, one atomic per window by
-   * thread 0).  The workgroup always knows its next THREE windows (wA now, wB, wC): the sort key of an entry is two
-   * dependent loads away (hit slot -> its category), issued one iteration (category) and two iterations (slot) ahead,
-   * so the chain hides behind the previous windows' shading; and the atomic for the window after those is issued a
-   * whole iteration before its value is broadcast, so nobody waits for it. */
-  const uint32_t nc = gridDim.x < 8u ? gridDim.x : 8u, cc = blockIdx.x % nc;
-  const uint32_t total_win = (uint32_t)(((unsigned long long)n + blockDim.x - 1) / blockDim.x);
-  const uint32_t win_limit = cc < total_win ? (total_win - cc + nc - 1u) / nc : 0u; /* windows cc, cc + nc, ... */
-  uint32_t pending = 0u; /* thread 0: the hand-out counter's value for the window after wC */
-#if PT_DYNAMIC_WINDOWS
-  if (threadIdx.x == 0) {
-    lds_win[0] = atomicAdd(work + cc, 3u);
-    pending = atomicAdd(work + cc, 1u);
-  }
-  __syncthreads();
-  uint32_t wA = lds_win[0], wB = wA + 1u, wC = wA + 2u;
-  __syncthreads();
-#else
-  /* static stride over the windows of this counter's share: workgroup j of the gridDim / nc that share it takes
-   * windows j, j + gridDim / nc, ... (grids are multiples of 8 or smaller than 8) */
-  const uint32_t wg_per_ctr = (gridDim.x + nc - 1u) / nc;
-  uint32_t wA = blockIdx.x / nc, wB = wA + wg_per_ctr, wC = wB + wg_per_ctr;
-#endif
-#define PT_WIN_BASE(w) (((w) < win_limit) ? ((w) * nc + cc) * blockDim.x : 0xffffffffu) /* 0xffffffff: no such window */
-  int pf_key = PT_CAT_NONE, pf_slot = -2; /* key of this iteration's entry; slot of the next iteration's (-2: none) */
-  if (PT_SHADE_SORT && PT_SHADE_PREFETCH && !PRIMARY) {
-    const uint32_t bA = PT_WIN_BASE(wA), bB = PT_WIN_BASE(wB);
-    if (bA != 0xffffffffu && bA + threadIdx.x < n) {
-      const int sl = hits.slot[bA + threadIdx.x];
-      pf_key = sl < 0 ? PT_CAT_MISS : (int)sc.slot_cat[sl];
-    }
-    if (bB != 0xffffffffu && bB + threadIdx.x < n) pf_slot = hits.slot[bB + threadIdx.x];
-  }
-#if PT_SHADE_TIMING
-  /* diagnostic build (tools/shade_timing.sh): where a wave's life goes, in shader clocks, summed per bounce into work[16..] */
-  unsigned long long tm_sort = 0, tm_entry = 0, tm_append = 0, tm_store = 0, tm_wait = 0;
-  const unsigned long long tm_begin = __builtin_readcyclecounter();
-#define PT_TM(var, since) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long now_ = __builtin_readcyclecounter(); var += now_ - since; since = now_; __builtin_amdgcn_sched_barrier(0); } while (0)
-#else
-#define PT_TM(var, since) do { } while (0)
-#endif
-  for (int it = 0; wA < win_limit; ++it) {
-#if PT_SHADE_TIMING
-    unsigned long long tm_t = __builtin_readcyclecounter();
-#endif
-    const uint32_t base_i = PT_WIN_BASE(wA);
-    /* the window after wC: broadcast what thread 0 fetched an iteration ago, fetch the one after it */
-#if PT_DYNAMIC_WINDOWS
-    if (threadIdx.x == 0) {
-      lds_win[it & 1] = pending;
-      pending = atomicAdd(work + cc, 1u);
-    }
-#endif
-    uint32_t i = base_i + threadIdx.x;
-    if (PT_SHADE_SORT && !PRIMARY) {
-      int key = PT_CAT_NONE;
-      if (PT_SHADE_PREFETCH) {
-        key = pf_key;
-        /* next iteration's key from the slot fetched an iteration ago; the slot after that */
-        pf_key = pf_slot == -2 ? PT_CAT_NONE : (pf_slot < 0 ? PT_CAT_MISS : (int)sc.slot_cat[pf_slot]);
-        const uint32_t bC = PT_WIN_BASE(wC);
-        pf_slot = (bC != 0xffffffffu && bC + threadIdx.x < n) ? hits.slot[bC + threadIdx.x] : -2;
-      } else if (i < n) {
-        const int sl = hits.slot[i];
-        key = sl < 0 ? PT_CAT_MISS : (int)sc.slot_cat[sl];
-      }
-      i = base_i + pt_block_sort_by_category(key, lds_cnt, lds_perm);
-    }
-    PT_TM(tm_sort, tm_t);
-    PtShadeOut so;
-    pt_shade_entry<EMIT, PRIMARY, PT_CAT_NONE>(sc, q, hits, contrib, alpha, bounce, last_bounce, g, i, i < n, so);
-    PT_TM(tm_entry, tm_t);
-    const bool keep = so.keep;
-    const V3 n_o = so.n_o, n_d = so.n_d, n_attn = so.n_attn, n_emit = so.n_emit;
-    const uint32_t id = so.id;
-    const int offset = so.offset;
-#if PT_APPEND_BINS > 1
-    const int octant = pt_bin_key(sc, n_o, n_d);
-    /* with the category sort on, its three barriers separate one append from the next */
-#if PT_SHADE_TIMING
-    const uint32_t dst = pt_block_append_binned<!(PT_SHADE_SORT && !PRIMARY)>(out.count, keep, octant, lds_bins, &tm_wait);
-#else
-    const uint32_t dst = pt_block_append_binned<!(PT_SHADE_SORT && !PRIMARY)>(out.count, keep, octant, lds_bins);
-#endif
-#else
-    const uint32_t dst = pt_block_append(out.count, keep, lds_append);
-#endif
-    PT_TM(tm_append, tm_t);
-    if (keep) pt_q_store<EMIT>(out, dst, n_o, n_d, n_attn, n_emit, id, offset);
-    PT_TM(tm_store, tm_t);
-    /* every path through the append above crossed a workgroup barrier after thread 0's store to lds_win[it & 1],
-     * and the next store to that word is two iterations away */
-    wA = wB;
-    wB = wC;
-#if PT_DYNAMIC_WINDOWS
-    wC = lds_win[it & 1];
-#else
-    wC = wC + wg_per_ctr;
-#endif
-  }
-#undef PT_WIN_BASE
-#if PT_SHADE_TIMING
-  if (pt_lane() == 0) {
-    const unsigned long long life = __builtin_readcyclecounter() - tm_begin;
-    atomicAdd(work + 16, (uint32_t)(tm_sort >> 8));
-    atomicAdd(work + 17, (uint32_t)(tm_entry >> 8));
-    atomicAdd(work + 18, (uint32_t)(tm_append >> 8));
-    atomicAdd(work + 19, (uint32_t)(tm_store >> 8));
-    atomicAdd(work + 20, (uint32_t)(life >> 8));
-    atomicAdd(work + 21, 1u);
-    atomicAdd(work + 22, (uint32_t)(tm_wait >> 8));
-  }
-#endif
-#undef PT_TM
-}
 
 /* ------------------------------------------------------------------ the shade stage without workgroup barriers
- * k_shade above sorts a 512-entry window by category and appends its survivors with one atomic: both need workgroup
- * barriers, and between two barriers the window's waves run materials of very different length (a miss is ~150
- * instructions, a checker Lambertian ~1200).  Measured with the kernel's own clock (tools/shade_timing.sh, bounce 1 of the
- * headline frame): 33 % of a wave's life is spent at the append's first barrier waiting for the window's slowest wave,
- * 10 % behind the append's atomic, 12 % in the sort, 39 % in the segment's arithmetic.
+ * Rounds 1-2 shaded category-sorted 512-entry windows (workgroup barriers around a sort and an append): between two barriers the
+ * window's waves ran materials of very different length (a miss is ~150 instructions, a checker Lambertian ~1200), and the
+ * kernel's own clock showed 33 % of a wave's life at the append's first barrier waiting for the window's slowest wave, 10 %
+ * behind the append's atomic, 12 % in the sort, 39 % in the segment's arithmetic (removed in round 5).
  *
  * Here a wave never waits for another one (except while a full output block is being replaced, below):
  *  - POOLS.  Every wave owns one list of queue indices per category in LDS (128 entries each).  It classifies raw chunks of 64
@@ -2702,9 +2115,10 @@ __global__ __launch_bounds__(PT_SHADE_BLOCK, PT_SHADE_WAVES) void k_shade(PtScen
  * reads its own survivors back in the next bounce of the same launch) */
 template <bool EMIT>
 __device__ __forceinline__ void pt_pool_push(const PtSceneDev& sc, const PtQueue& out, const PtShadeOut& so, uint32_t* lds_out,
-                                             uint32_t* blk_list = nullptr, uint32_t* blk_n = nullptr) {
+                                             uint32_t* blk_list = nullptr, uint32_t* blk_n = nullptr, bool one_bin = false) {
   const int lane = pt_lane();
-  const int bin = pt_bin_key<PT_POOL_BINS>(sc, so.n_o, so.n_d);
+  /* one_bin (wave-uniform): a workgroup whose rays would not fill a block does not spread them over eight (PtSolo) */
+  const int bin = one_bin ? 0 : pt_bin_key<PT_POOL_BINS>(sc, so.n_o, so.n_d);
   if (__ballot(so.keep) == 0) return;
   /* all bins at once: lane b < 8 holds bin b's survivor count and makes its reservation -- one LDS atomic instruction */
   uint32_t rank = 0, kk = 0;
@@ -2970,16 +2384,32 @@ __global__ __launch_bounds__(PT_POOL_THREADS, PT_SHADE_WAVES) void k_shade_pool(
  * buffer that holds the launch's input starts behind it), and the launch runs solo only if the buffers are large enough for
  * every remaining bounce's survivors and holes in the worst case.  Same walks, same shade steps, same sampler dimensions per bounce: the
  * results do not depend on the order of a queue, so they are the step-by-step launches' bit for bit. */
+/* a workgroup-wide lock in LDS for the few-instruction critical sections of the parked-walk pool (every lane of the wave calls both) */
+__device__ __forceinline__ void pt_lds_lock(uint32_t* l) {
+  if (pt_lane() == 0)
+    while (__hip_atomic_exchange(l, 1u, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != 0u) __builtin_amdgcn_s_sleep(1);
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+__device__ __forceinline__ void pt_lds_unlock(uint32_t* l) {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  if (pt_lane() == 0) __hip_atomic_store(l, 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+/* entries the parked-walk pool of a k_bounce workgroup of nw waves must hold: a wave takes a fresh chunk only while fewer than 64
+ * walks are parked and parks fewer than the cut when it ends; a resumed chunk takes 64 out before it can put any back */
+#define PT_PARK_CAP(nw, cut) (PT_WAVE + (nw) * (cut))
 struct PtSolo {
   uint32_t* flag;       /* per batch, zero at its start; null = never run solo */
   uint32_t max_entries; /* run solo when the input queue holds at most this many entries (0 = never) */
   int32_t max_bounces;
   uint32_t cap_entries; /* capacity of each of the two queues, in entries */
 };
+#ifndef PT_SOLO_ONE_BIN_CHUNKS
+#define PT_SOLO_ONE_BIN_CHUNKS 2 /* a workgroup whose input of a solo turn is at most this many chunks per wave puts all survivors into one bin */
+#endif
 #ifndef PT_SOLO_MAX_BLOCKS
 #define PT_SOLO_MAX_BLOCKS 256 /* output blocks a workgroup can note per bounce; a launch whose shares could need more does not run solo */
 #endif
-template <int MODE, bool COUNT, bool EMIT, bool PRIMARY, bool LDS_SCENE = true>
+template <int MODE, bool COUNT, bool EMIT, bool PRIMARY, bool LDS_SCENE = true, bool SOLO_T = false>
 __global__ __launch_bounds__(PT_BOUNCE_THREADS, PT_BOUNCE_WAVES) void k_bounce(PtSceneDev sc, PtQueue q, PtHits hits, PtQueue out, PtContrib contrib,
                                                                  const double* __restrict__ alpha, int bounce, int last_bounce, PtGenParams g,
                                                                  uint32_t n_primary, int stack_depth, uint32_t pool_off, uint4* susp,
@@ -2987,7 +2417,10 @@ __global__ __launch_bounds__(PT_BOUNCE_THREADS, PT_BOUNCE_WAVES) void k_bounce(P
   extern __shared__ __attribute__((aligned(64))) unsigned char lds_raw[];
   __shared__ uint32_t lds_out[PT_POOL_BINS];
   __shared__ uint32_t lds_chunk_ctr, lds_done;
-  constexpr bool SOLO = !PRIMARY && PT_DIAG == 0 && PT_DIAG_FLOOR == 0;
+  __shared__ uint32_t lds_park_n, lds_park_lock; /* the workgroup's parked walks (below) */
+  /* (a template switch, launched only when PTX_SOLO_ENTRIES asks for it: the loop around the bounces costs the kernel 6 - 11 VGPRs it does
+   * not have -- the instantiations without it keep 0 spilled registers) */
+  constexpr bool SOLO = SOLO_T && !PRIMARY && PT_DIAG == 0 && PT_DIAG_FLOOR == 0;
   __shared__ uint32_t lds_blk[SOLO ? 2 : 1][SOLO ? PT_SOLO_MAX_BLOCKS : 1]; /* the blocks this workgroup wrote in the bounce before / is writing now */
   __shared__ uint32_t lds_nblk[2];
   const int lane = pt_lane(), wave = (int)(threadIdx.x >> 6), nw = (int)(blockDim.x >> 6);
@@ -3019,7 +2452,7 @@ __global__ __launch_bounds__(PT_BOUNCE_THREADS, PT_BOUNCE_WAVES) void k_bounce(P
 #if PT_DIAG_FLOOR == 2
   if (gridDim.x > 0) return; /* diagnostic build (tools/README.md): what a launch costs before it does anything */
 #endif
-  if (threadIdx.x == 0) { lds_chunk_ctr = 0u; lds_done = 0u; lds_nblk[0] = lds_nblk[1] = 0u; }
+  if (threadIdx.x == 0) { lds_chunk_ctr = 0u; lds_done = 0u; lds_nblk[0] = lds_nblk[1] = 0u; lds_park_n = 0u; lds_park_lock = 0u; }
   if (threadIdx.x < PT_POOL_BINS) lds_out[threadIdx.x] = (PT_POOL_NO_BLOCK << 12) | (uint32_t)PT_POOL_BLOCK; /* "full": the first push brings a block */
   PtSceneView sv = pt_scene_view<MODE, LDS_SCENE, StackT>(sc, lds_raw, stack_depth); /* LDS_SCENE: ends with the workgroup's only barrier (SOLO: per bounce, two more) */
   if (!LDS_SCENE) {
@@ -3050,8 +2483,14 @@ __global__ __launch_bounds__(PT_BOUNCE_THREADS, PT_BOUNCE_WAVES) void k_bounce(P
   constexpr bool TAIL = CUT > 0 && !(PRIMARY && LDS_SCENE); /* LDS scenes: camera rays walk as a packet (pt_trace_packet) and finish together */
   constexpr bool TAIL_UV = TAIL && MODE == PT_MODE_ARRAY;
   constexpr bool TAIL_W = TAIL && !LDS_SCENE; /* 32-bit node index and slot: a third 16 bytes (as in k_trace) */
-  uint4* my_susp = susp + ((size_t)blockIdx.x * nw + wave) * (PT_WAVE * 3);
-  uint32_t n_susp = 0; /* wave-uniform */
+  /* Parked walks (PtTailCtl) are pooled per WORKGROUP in LDS, behind the shade pools: whichever wave next looks for work and finds
+   * 64 of them walks them as a dense chunk.  (Round 4 kept them per wave, in global memory: a wave had to collect 48 of its own
+   * stragglers -- three or four cut chunks -- before it could resume any, which is what held the cut at 16 rays.)  16-byte entries
+   * {queue index, node | slot << 16, t}; + {u, v} for triangle hits; + {node, slot} as 32-bit words on the walk from HBM / L2. */
+  const uint32_t park_cap = (uint32_t)PT_PARK_CAP(nw, CUT);
+  uint4* const park0 = (uint4*)(lds_raw + pool_off + (size_t)nw * PT_N_SHADE_CAT * 128 * sizeof(uint2));
+  uint4* const park_uv = park0 + park_cap;
+  uint4* const park_w = park_uv + (TAIL_UV ? park_cap : 0u);
   bool more = true;    /* wave-uniform: the workgroup's share of the queue is not exhausted */
   unsigned long long c_nodes = 0, c_prims = 0, c_floor = 0, c_seg = 0, c_filter[2] = {0, 0}; /* COUNT: as in k_trace */
   /* SOLO: the bounce this workgroup is at, its queues, and whether its input is the block list it noted in the bounce before */
@@ -3071,7 +2510,8 @@ __global__ __launch_bounds__(PT_BOUNCE_THREADS, PT_BOUNCE_WAVES) void k_bounce(P
  for (;;) { /* (one turn per bounce; a launch that does not run solo leaves after the first) */
   for (;;) {
     PT_TM5(c_floor);
-    const bool input_left = more || n_susp > 0;
+    const uint32_t park_hint = TAIL ? __hip_atomic_load(&lds_park_n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 0u; /* (wave-uniform: one LDS word) */
+    const bool input_left = more || park_hint > 0;
     /* the fullest pool that holds a whole step; once nothing is left to walk, the fullest pool */
     int c = -1;
     uint32_t best = input_left ? (uint32_t)(PT_WAVE - 1) : 0u;
@@ -3107,7 +2547,8 @@ __global__ __launch_bounds__(PT_BOUNCE_THREADS, PT_BOUNCE_WAVES) void k_bounce(P
 #undef PT_POOL_STEP
       if (PT_DIAG == 7) PT_TM5(c_floor);
       if (c != PT_CAT_MISS && !last_bounce) {
-        if (SOLO && solo_on) pt_pool_push<EMIT>(sc, out, so, lds_out, lds_blk[SOLO ? (cur_list ^ 1u) : 0u], &lds_nblk[cur_list ^ 1u]);
+        if (SOLO && solo_on) pt_pool_push<EMIT>(sc, out, so, lds_out, lds_blk[SOLO ? (cur_list ^ 1u) : 0u], &lds_nblk[cur_list ^ 1u],
+                                                own_blocks && own_chunks <= (uint32_t)(PT_SOLO_ONE_BIN_CHUNKS * nw));
         else pt_pool_push<EMIT>(sc, out, so, lds_out);
       }
       if (PT_DIAG == 6) PT_TM5(c_floor);
@@ -3120,26 +2561,39 @@ __global__ __launch_bounds__(PT_BOUNCE_THREADS, PT_BOUNCE_WAVES) void k_bounce(P
     bool resume = false, valid = false;
     uint32_t i = 0;
     uint4 parked = make_uint4(0, 0, 0, 0), parked_uv = make_uint4(0, 0, 0, 0), parked_w = make_uint4(0, 0, 0, 0);
-    if (TAIL && (n_susp > (uint32_t)(PT_WAVE - CUT) || (!more && n_susp > 0))) {
+    if (TAIL && (park_hint >= (uint32_t)PT_WAVE || (!more && park_hint > 0))) {
+      /* 64 parked walks (the most recently parked: a stack), or what is left once this wave's share of the input is exhausted */
+      pt_lds_lock(&lds_park_lock);
+      const uint32_t np = __hip_atomic_load(&lds_park_n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      const uint32_t take = (np >= (uint32_t)PT_WAVE || !more) ? (np < (uint32_t)PT_WAVE ? np : (uint32_t)PT_WAVE) : 0u;
+      const uint32_t base = np - take;
+      if ((uint32_t)lane < take) {
+        parked = park0[base + lane];
+        if (TAIL_UV) parked_uv = park_uv[base + lane];
+        if (TAIL_W) parked_w = park_w[base + lane];
+      }
+      if (lane == 0 && take) __hip_atomic_store(&lds_park_n, base, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      pt_lds_unlock(&lds_park_lock);
+      if (take == 0u) continue; /* (another wave was faster) */
       resume = true;
-      valid = (uint32_t)lane < n_susp;
-      if (valid) parked = my_susp[lane];
-      if (TAIL_UV && valid) parked_uv = my_susp[PT_WAVE + lane];
-      if (TAIL_W && valid) parked_w = my_susp[2 * PT_WAVE + lane];
+      valid = (uint32_t)lane < take;
       i = parked.x;
-      n_susp = 0;
     } else {
+      if (!more) continue; /* (only here when the hint and the pool disagreed a moment ago) */
       /* the next chunk of the workgroup's share (runs of PT_POOL_RUN consecutive chunks, dealt round-robin, as in k_shade_pool;
        * taking a chunk one turn ahead and touching its ray records cost 2 % in round 3 and 3.5 % (cornell 5 %) in round 4: a line
        * touched ~10 us early is evicted from the L2 again before the wave comes back for it, and is then fetched twice) */
       uint32_t unit = 0u;
       if (lane == 0) unit = __hip_atomic_fetch_add(&lds_chunk_ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       unit = (uint32_t)__builtin_amdgcn_readfirstlane((int)unit);
-      if (SOLO && own_blocks) { /* the workgroup's own blocks of the bounce before, PT_POOL_BLOCK / 64 chunks each (holes marked) */
+      if (SOLO && own_blocks) { /* the workgroup's own blocks of the bounce before (block | entries written << 20), PT_POOL_BLOCK / 64 chunks each */
         more = unit < own_chunks;
         if (more) {
-          i = lds_blk[SOLO ? cur_list : 0u][unit / (PT_POOL_BLOCK / PT_WAVE)] * (uint32_t)PT_POOL_BLOCK + (unit % (PT_POOL_BLOCK / PT_WAVE)) * PT_WAVE + (uint32_t)lane;
-          valid = true;
+          const uint32_t e = lds_blk[SOLO ? cur_list : 0u][unit / (PT_POOL_BLOCK / PT_WAVE)];
+          const uint32_t fill = e >> 20, off = (unit % (PT_POOL_BLOCK / PT_WAVE)) * PT_WAVE;
+          if (off >= fill) continue; /* (wave-uniform) the unwritten part of a bin's last block: nothing to read, nothing was marked */
+          i = (e & 0xfffffu) * (uint32_t)PT_POOL_BLOCK + off + (uint32_t)lane;
+          valid = off + (uint32_t)lane < fill;
         }
       } else {
       unit = (unit / PT_POOL_RUN) * (n_wg * PT_POOL_RUN) + blockIdx.x * PT_POOL_RUN + (unit % PT_POOL_RUN);
@@ -3202,15 +2656,18 @@ __global__ __launch_bounds__(PT_BOUNCE_THREADS, PT_BOUNCE_WAVES) void k_bounce(P
     if (TAIL) {
       const unsigned long long pm = __ballot(park);
       if (pm != 0) {
+        pt_lds_lock(&lds_park_lock);
+        const uint32_t base = __hip_atomic_load(&lds_park_n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         if (park) {
-          const uint32_t k = n_susp + (uint32_t)__popcll(pm & ((1ull << lane) - 1ull));
-          my_susp[k] = make_uint4(i, tc.node | ((uint32_t)(r.slot < 0 ? 0xffff : r.slot) << 16),
-                                  (uint32_t)__double2loint(r.t), (uint32_t)__double2hiint(r.t));
-          if (TAIL_W) my_susp[2 * PT_WAVE + k] = make_uint4(tc.node, (uint32_t)r.slot, 0u, 0u);
+          const uint32_t k = base + (uint32_t)__popcll(pm & ((1ull << lane) - 1ull));
+          park0[k] = make_uint4(i, tc.node | ((uint32_t)(r.slot < 0 ? 0xffff : r.slot) << 16),
+                                (uint32_t)__double2loint(r.t), (uint32_t)__double2hiint(r.t));
+          if (TAIL_W) park_w[k] = make_uint4(tc.node, (uint32_t)r.slot, 0u, 0u);
           if (TAIL_UV)
-            my_susp[PT_WAVE + k] = make_uint4((uint32_t)__double2loint(r.u), (uint32_t)__double2hiint(r.u), (uint32_t)__double2loint(r.v), (uint32_t)__double2hiint(r.v));
+            park_uv[k] = make_uint4((uint32_t)__double2loint(r.u), (uint32_t)__double2hiint(r.u), (uint32_t)__double2loint(r.v), (uint32_t)__double2hiint(r.v));
         }
-        n_susp += (uint32_t)__popcll(pm);
+        if (lane == 0) __hip_atomic_store(&lds_park_n, base + (uint32_t)__popcll(pm), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        pt_lds_unlock(&lds_park_lock);
       }
     }
     /* this wave's own stores (hit records, parked states, pool entries) before its own later loads of them: program order
@@ -3231,15 +2688,21 @@ __global__ __launch_bounds__(PT_BOUNCE_THREADS, PT_BOUNCE_WAVES) void k_bounce(P
    * opens; the unused tails of the part-filled blocks become holes, the blocks noted by the pushes become the input. */
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); /* the survivors' records, for the other waves of this workgroup */
   __syncthreads();
-  for (int b = 0; b < PT_POOL_BINS; ++b) {
-    const uint32_t st = lds_out[b];
-    const uint32_t blk = st >> 12, pos = st & 0xfffu;
-    if (blk == PT_POOL_NO_BLOCK) continue;
-    for (uint32_t e = pos + threadIdx.x; e < (uint32_t)PT_POOL_BLOCK; e += blockDim.x)
-      out.ray[(size_t)blk * PT_POOL_BLOCK + e].dx = __hiloint2double((int)PT_HOLE_HI, 0);
+  {
+    /* how far each noted block was written: a bin's last block up to its cursor, every other one completely.  The next turn reads
+     * exactly that much -- no holes are marked, none are looked for */
+    const uint32_t nb = lds_nblk[cur_list ^ 1u];
+    for (uint32_t t = threadIdx.x; t < nb; t += blockDim.x) {
+      const uint32_t blk = lds_blk[SOLO ? (cur_list ^ 1u) : 0u][t];
+      uint32_t fill = (uint32_t)PT_POOL_BLOCK;
+      for (int b = 0; b < PT_POOL_BINS; ++b) {
+        const uint32_t st = lds_out[b];
+        if ((st >> 12) == blk) fill = st & 0xfffu;
+      }
+      lds_blk[SOLO ? (cur_list ^ 1u) : 0u][t] = blk | (fill << 20);
+    }
+    own_chunks = nb * (uint32_t)(PT_POOL_BLOCK / PT_WAVE);
   }
-  own_chunks = lds_nblk[cur_list ^ 1u] * (uint32_t)(PT_POOL_BLOCK / PT_WAVE);
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); /* the holes */
   __syncthreads(); /* everybody has read the bins and the list's length */
   if (threadIdx.x == 0) {
     lds_chunk_ctr = 0u;
@@ -3295,127 +2758,6 @@ __global__ __launch_bounds__(PT_BOUNCE_THREADS, PT_BOUNCE_WAVES) void k_bounce(P
     if (blk == PT_POOL_NO_BLOCK) continue;
     for (uint32_t e = pos + (uint32_t)lane; e < (uint32_t)PT_POOL_BLOCK; e += PT_WAVE)
       out.ray[(size_t)blk * PT_POOL_BLOCK + e].dx = __hiloint2double((int)PT_HOLE_HI, 0);
-  }
-}
-
-/* ------------------------------------------------------------------ per-stage queues for the shade stage
- * One index list per shading category (miss / Lambertian solid / Lambertian checker / metal / dielectric), built by
- * k_classify right after the trace launch, and one shade kernel per list (k_shade_cat).  With ONE kernel over a
- * category-sorted 512-entry window, the window's waves ran different materials of very different length (a miss is
- * ~150 instructions, a checker Lambertian ~1200) between the same workgroup barriers: the short waves sat parked at the
- * barrier (SQ_WAIT_ANY 72 % of a wave's life, profiles/r02a_sq.json) and the register file was sized for the sum of
- * all five paths.  Per-category kernels keep every wave of a workgroup on the same path, need no sort, and are
- * register-allocated for one material each.  A list keeps queue order, so reads of the queues stay clustered. */
-struct PtCatLists {
-  uint32_t* idx;      /* PT_N_SHADE_CAT lists of `cap` entries each: queue (or virtual primary) indices */
-  uint32_t* count;    /* PT_N_SHADE_CAT list lengths (device, zero at launch) */
-  size_t cap;
-};
-#define PT_CLASSIFY_BLOCK 1024
-#define PT_CLASSIFY_ROWS 4 /* entries per thread per iteration: 4096 entries, 5 atomics */
-
-template <bool PRIMARY>
-__global__ __launch_bounds__(PT_CLASSIFY_BLOCK) void k_classify(PtSceneDev sc, const uint32_t* __restrict__ q_count, PtHits hits,
-                                                               PtGenParams g, uint32_t n_primary, PtCatLists lists) {
-  __shared__ uint32_t cnt[PT_N_SHADE_CAT][PT_CLASSIFY_ROWS * (PT_CLASSIFY_BLOCK / 64) + 1]; /* [category][row], row = j * 16 + wave */
-  __shared__ uint32_t base_of[PT_N_SHADE_CAT];
-  const uint32_t n = PRIMARY ? n_primary : *q_count;
-  const int lane = pt_lane(), wave = (int)(threadIdx.x >> 6);
-  constexpr int kRows = PT_CLASSIFY_ROWS * (PT_CLASSIFY_BLOCK / 64);
-  const unsigned long long span = (unsigned long long)PT_CLASSIFY_BLOCK * PT_CLASSIFY_ROWS;
-  for (unsigned long long base = (unsigned long long)blockIdx.x * span; base < n; base += (unsigned long long)gridDim.x * span) {
-    int cat[PT_CLASSIFY_ROWS];
-    uint32_t rank[PT_CLASSIFY_ROWS];
-#pragma unroll
-    for (int j = 0; j < PT_CLASSIFY_ROWS; ++j) {
-      const unsigned long long i = base + (unsigned long long)j * PT_CLASSIFY_BLOCK + threadIdx.x;
-      int c = PT_CAT_NONE;
-      if (i < n) {
-        bool ok = true;
-        if (PRIMARY) ok = pt_primary_decode(g, (uint32_t)i).valid;
-        if (ok) {
-          const int sl = hits.slot[i];
-          c = sl < 0 ? PT_CAT_MISS : (int)sc.slot_cat[sl];
-        }
-      }
-      cat[j] = c;
-      rank[j] = 0;
-#pragma unroll
-      for (int k = 0; k < PT_N_SHADE_CAT; ++k) {
-        const unsigned long long m = __builtin_amdgcn_ballot_w64(c == k);
-        if (c == k) rank[j] = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-        if (lane == 0) cnt[k][j * (PT_CLASSIFY_BLOCK / 64) + wave] = (uint32_t)__popcll(m);
-      }
-    }
-    __syncthreads();
-    if (wave < PT_N_SHADE_CAT) { /* wave k: exclusive prefix over category k's rows (64 of them), one atomic */
-      const uint32_t v = lane < kRows ? cnt[wave][lane] : 0u;
-      uint32_t incl = v;
-      for (int off = 1; off < 64; off <<= 1) {
-        const uint32_t up = (uint32_t)__shfl_up((int)incl, off, 64);
-        if (lane >= off) incl += up;
-      }
-      const uint32_t total = (uint32_t)__shfl((int)incl, 63, 64);
-      if (lane < kRows) cnt[wave][lane] = incl - v;
-      if (lane == 0) base_of[wave] = total ? atomicAdd(lists.count + wave, total) : 0u;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int j = 0; j < PT_CLASSIFY_ROWS; ++j) {
-      const int c = cat[j];
-      if (c < PT_N_SHADE_CAT) {
-        const unsigned long long i = base + (unsigned long long)j * PT_CLASSIFY_BLOCK + threadIdx.x;
-        lists.idx[(size_t)c * lists.cap + base_of[c] + cnt[c][j * (PT_CLASSIFY_BLOCK / 64) + wave] + rank[j]] = (uint32_t)i;
-      }
-    }
-    __syncthreads(); /* cnt / base_of are rewritten by the next iteration */
-  }
-}
-
-/* The shade stage for ONE category's list.  Same per-segment arithmetic as k_shade (pt_shade_entry); survivors are
- * appended binned by direction octant exactly as there.  PT_CAT_MISS writes contributions only: no append, no barrier. */
-#ifndef PT_SHADE_CAT_WAVES
-#define PT_SHADE_CAT_WAVES 4
-#endif
-template <bool EMIT, bool PRIMARY, int CAT>
-__global__ __launch_bounds__(PT_SHADE_BLOCK, PT_SHADE_CAT_WAVES) void k_shade_cat(PtSceneDev sc, PtQueue q, PtHits hits, PtQueue out, PtContrib contrib,
-                                                const double* __restrict__ alpha, int bounce, int last_bounce,
-                                                PtGenParams g, PtCatLists lists, uint32_t* work) {
-  __shared__ uint32_t lds_bins[65];
-  __shared__ uint32_t lds_win[2];
-  const uint32_t n = lists.count[CAT];
-  const uint32_t* __restrict__ list = lists.idx + (size_t)CAT * lists.cap;
-  const uint32_t nc = gridDim.x < 8u ? gridDim.x : 8u, cc = blockIdx.x % nc;
-  const uint32_t total_win = (uint32_t)(((unsigned long long)n + blockDim.x - 1) / blockDim.x);
-  const uint32_t win_limit = cc < total_win ? (total_win - cc + nc - 1u) / nc : 0u; /* windows cc, cc + nc, ... */
-  if (win_limit == 0) return; /* workgroup-uniform */
-  /* windows are handed out as in k_shade: thread 0 fetches one ahead, the value is broadcast through LDS */
-  uint32_t pending = 0u;
-  if (threadIdx.x == 0) {
-    lds_win[0] = atomicAdd(work + cc, 1u);
-    pending = atomicAdd(work + cc, 1u);
-  }
-  __syncthreads();
-  uint32_t wA = lds_win[0];
-  __syncthreads();
-  for (int it = 0; wA < win_limit; ++it) {
-    if (threadIdx.x == 0) {
-      lds_win[it & 1] = pending;
-      pending = atomicAdd(work + cc, 1u);
-    }
-    const uint32_t j = (wA * nc + cc) * blockDim.x + threadIdx.x;
-    const bool live = j < n;
-    const uint32_t i = live ? list[j] : 0u;
-    PtShadeOut so;
-    pt_shade_entry<EMIT, PRIMARY, CAT>(sc, q, hits, contrib, alpha, bounce, last_bounce, g, i, live, so);
-    if (CAT != PT_CAT_MISS) {
-      const int octant = pt_bin_key(sc, so.n_o, so.n_d);
-      const uint32_t dst = pt_block_append_binned<true>(out.count, so.keep, octant, lds_bins);
-      if (so.keep) pt_q_store<EMIT>(out, dst, so.n_o, so.n_d, so.n_attn, so.n_emit, so.id, so.offset);
-    } else {
-      __syncthreads(); /* lds_win */
-    }
-    wA = lds_win[it & 1];
   }
 }
 

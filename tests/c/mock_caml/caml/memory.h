@@ -19,5 +19,9 @@ void mock_caml_root(value*);
 #define CAMLreturn0 do { (void)caml__frame_; return; } while (0)
 #define CAMLdrop ((void)caml__frame_)
 void caml_modify(value*, value);
+/* generational global roots (memory.h of the runtime): the cell must not move while it is registered */
+void caml_register_generational_global_root(value*);
+void caml_remove_generational_global_root(value*);
+void caml_modify_generational_global_root(value*, value);
 #define Store_field(block, i, v) caml_modify(&Field(block, i), v)
 #endif

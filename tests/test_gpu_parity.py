@@ -412,10 +412,7 @@ def test_random_configs_raw_sums_bitwise(P, oracle, seed, monkeypatch):
     kind = ["shirley", "shirley_no_simd", "cornell", "ganesha"][int(rng.integers(0, 4))]
     d = {"shirley": lambda: oracle.desc_shirley(w, h), "shirley_no_simd": lambda: oracle.desc_shirley(w, h, no_simd=True),
          "cornell": lambda: oracle.desc_cornell(w, h), "ganesha": lambda: oracle.desc_ganesha_like(w, h, n_target=4000)}[kind]()
-    monkeypatch.setenv("PTX_TRACE_STREAM", str(int(rng.integers(0, 2))))  # both trace kernels on every kind of scene
     monkeypatch.setenv("PTX_STREAMS", str(int(rng.integers(1, 5))))  # batches in flight
-    monkeypatch.setenv("PTX_SHADE_SPLIT", str(int(rng.integers(0, 2))))  # per-category stage queues (wins over PTX_SHADE_POOL)
-    monkeypatch.setenv("PTX_SHADE_POOL", str(int(rng.integers(0, 2))))  # barrier-free pooled shade kernel / category-sorted windows
     monkeypatch.setenv("PTX_TRACE_BLOCK", str(int(rng.choice([0, 64, 256, 512, 1024]))))  # trace workgroup size (0 = by schedule)
     monkeypatch.setenv("PTX_TRACE_WGS", str(int(rng.integers(0, 4))))  # trace workgroups per CU (0 = as many as fit)
     monkeypatch.setenv("PTX_SHADE_WGS", str(int(rng.integers(0, 4))))  # pooled shade workgroups per CU (0 = by schedule)
@@ -636,34 +633,31 @@ def test_queued_frames_with_different_depths_on_a_side_stream(P, oracle):
 
 
 @pytest.mark.parametrize("kind", ["shirley", "cornell", "ganesha"])
-def test_the_three_shade_stage_implementations_agree(P, oracle, kind, monkeypatch):
-    """The default k_shade_pool (per-wave category pools, blocked output queue with holes), k_shade (category-sorted
-    windows, PTX_SHADE_POOL=0) and PTX_SHADE_SPLIT=1 (k_classify + one k_shade_cat per material category) against the
-    oracle: raw sums bit for bit, per-sample radiance bit for bit, the segment count (holes are not rays), with emitters
+def test_two_kernel_schedule_against_the_oracle(P, oracle, kind, monkeypatch):
+    """PTX_FUSED=0 / PTX_FUSED_GLOBAL=0: k_trace + k_shade_pool (per-wave category pools, blocked output queue with holes) -- what
+    runs where k_bounce's LDS does not fit, for the camera rays with PTX_FUSED=1, and in ptx_trace_samples -- against the
+    oracle: raw sums bit for bit, per-sample radiance bit for bit, the work counters (holes are not rays), with emitters
     (cornell) and triangles (ganesha)."""
     torch = pytest.importorskip("torch")
     w, h, spp, depth = 160, 100, 5, 8
     d = {"shirley": lambda: oracle.desc_shirley(w, h), "cornell": lambda: oracle.desc_cornell(w, h),
          "ganesha": lambda: oracle.desc_ganesha_like(w, h, n_target=5000)}[kind]()
     c = oracle.Scene(d.ptr, d).render(w, h, spp, depth, threads=8, want_raw=True, count=True)
-    raws = []
-    for split, pool in (("0", "1"), ("0", "0"), ("1", "1")):
-        monkeypatch.setenv("PTX_SHADE_SPLIT", split)  # read when the scene handle is created
-        monkeypatch.setenv("PTX_SHADE_POOL", pool)
-        g = P.Scene(d.ptr, 0, keepalive=d)
-        raw = torch.zeros((h, w, 3), dtype=torch.float64, device="cuda:0")
-        st = g.render_raw_device(P.render_params(w, h, spp, depth, passes_per_batch=2, count_work=True), raw.data_ptr())
-        for k in ("segments", "nodes_tested", "prims_tested"):
-            assert st[k] == c["counters"][k], (split, pool, k)
-        raws.append(raw.cpu().numpy())
-        rng = np.random.default_rng(4)
-        xs, ys, ps = rng.integers(0, w, 4000), rng.integers(0, h, 4000), rng.integers(0, spp, 4000)
-        g_rgb, _ = g.trace_samples(w, h, spp, depth, xs, ys, ps)
-        o_rgb, _ = oracle.Scene(d.ptr, d).trace_samples(w, h, spp, depth, xs, ys, ps)
-        assert np.array_equal(bits(g_rgb), bits(o_rgb)), f"split={split} pool={pool}: per-sample radiance differs from the oracle"
-        g.close()
-    for r in raws:
-        assert np.array_equal(bits(r), bits(c["raw"]))
+    monkeypatch.setenv("PTX_FUSED", "0")  # read when the scene handle is created
+    monkeypatch.setenv("PTX_FUSED_GLOBAL", "0")
+    g = P.Scene(d.ptr, 0, keepalive=d)
+    raw = torch.zeros((h, w, 3), dtype=torch.float64, device="cuda:0")
+    st = g.render_raw_device(P.render_params(w, h, spp, depth, passes_per_batch=2, count_work=True, time_kernels=True), raw.data_ptr())
+    for k in ("segments", "nodes_tested", "prims_tested"):
+        assert st[k] == c["counters"][k], k
+    assert st["kernel_launches"]["bounce"] == 0 and st["kernel_launches"]["trace"] == st["kernel_launches"]["shade"] == 3 * depth
+    assert np.array_equal(bits(raw.cpu().numpy()), bits(c["raw"]))
+    rng = np.random.default_rng(4)
+    xs, ys, ps = rng.integers(0, w, 4000), rng.integers(0, h, 4000), rng.integers(0, spp, 4000)
+    g_rgb, _ = g.trace_samples(w, h, spp, depth, xs, ys, ps)
+    o_rgb, _ = oracle.Scene(d.ptr, d).trace_samples(w, h, spp, depth, xs, ys, ps)
+    assert np.array_equal(bits(g_rgb), bits(o_rgb)), "per-sample radiance differs from the oracle"
+    g.close()
 
 
 @pytest.mark.parametrize("num_bins,cutoff", [(4, 4), (8, 8), (16, 2), (64, 12)])
@@ -683,14 +677,12 @@ def test_gpu_bvh_build_other_bin_counts_and_cutoffs(P, oracle, num_bins, cutoff)
     g.close()
 
 
-@pytest.mark.parametrize("pool", ["1", "0"])
-def test_state_after_the_first_scatter(P, oracle, pool, monkeypatch):
+def test_state_after_the_first_scatter(P, oracle):
     """ptx_debug_first_scatter reads the queue the first shade launch leaves behind -- with the pooled shade kernel a blocked
     queue whose part-filled blocks end in holes: every surviving path's next ray and attenuation must be the oracle's bit for bit,
     the same paths must be alive, and no hole may be taken for a path."""
     import ctypes as C
     from path_tracer_ocaml_amd import abi
-    monkeypatch.setenv("PTX_SHADE_POOL", pool)
     w, h, spp, depth = 200, 120, 8, 6
     d = oracle.desc_shirley(w, h)
     o = oracle.Scene(d.ptr, d)
