@@ -484,6 +484,9 @@ __device__ __forceinline__ uint32_t pt_stack_pop(const PtThreadOctTag*, int) { r
 #ifndef PT_DIAG
 #define PT_DIAG 0
 #endif
+#ifndef PT_DIAG_EXTRA_LOADS
+#define PT_DIAG_EXTRA_LOADS 0
+#endif
 #ifndef PT_PACKET_DEFER
 #define PT_PACKET_DEFER 1
 #endif
@@ -729,6 +732,16 @@ struct PtTraverser {
         /* (Leaf.length incl. the Simd_leaf padding to a multiple of 4, main.ml:179-186: for the work counter only) */
         nb = leaf ? ((MODE == PT_MODE_SIMD ? ((n_real + 3u) & ~3u) : n_real) | (PT_NODE_LEAF_AXIS << 30)) : w1.z;
         oct_skip = w1.w;
+#if PT_DIAG_EXTRA_LOADS /* diagnostic builds only: what one / two more 16-byte loads per node visit cost (the record's own line: no new misses) */
+        {
+          const uint4 x0 = p[(nd & 1u) ? -1 : 2];
+          if (x0.x == 0x7fc12345u && x0.w == 0x12345u) w1.x ^= 1u; /* (never true: keeps the load) */
+#if PT_DIAG_EXTRA_LOADS > 1
+          const uint4 x1 = p[(nd & 1u) ? -2 : 3];
+          if (x1.x == 0x7fc12345u && x1.w == 0x12345u) w1.y ^= 1u;
+#endif
+        }
+#endif
         mag = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(__uint_as_float(w0.x)), __builtin_fabsf(__uint_as_float(w0.y))),
                                               __builtin_fmaxf(__builtin_fabsf(__uint_as_float(w0.z)), __builtin_fabsf(__uint_as_float(w0.w)))),
                               __builtin_fmaxf(__builtin_fabsf(__uint_as_float(w1.x)), __builtin_fabsf(__uint_as_float(w1.y)))) * 1.000001f;
@@ -2764,9 +2777,11 @@ __global__ __launch_bounds__(PT_BOUNCE_THREADS, PT_BOUNCE_WAVES) void k_bounce(P
 /* ------------------------------------------------------------------ accumulate + film */
 /* raw[pix] += contributions of this batch's passes, in pass order (the order render_tile's pass loop
  * feeds the film, integrator.ml:96) */
-__global__ __launch_bounds__(256) void k_accum(PtContrib contrib, long long npix, int n_pass, double* __restrict__ raw) {
-  const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= npix) return;
+/* [p0, p1): the pixels of this launch -- the whole image, or one row slab of the frame's last batch (ptx_render: the film and the
+ * copy of slab k to the host run while slab k + 1 is still being summed) */
+__global__ __launch_bounds__(256) void k_accum(PtContrib contrib, long long npix, int n_pass, double* __restrict__ raw, long long p0, long long p1) {
+  const long long p = p0 + (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= p1) return;
   double r = raw[3 * p], g = raw[3 * p + 1], b = raw[3 * p + 2];
   for (int k = 0; k < n_pass; ++k) {
     const long long j = (long long)k * npix + p;
@@ -2801,9 +2816,9 @@ __device__ __forceinline__ long long pt_band_row(const PtBandMap& m, int y) {
  * (film_tile.ml:23-45); stitch_tile drops what falls outside the image (integrator.ml:114-128).  As a
  * gather: P = sum_taps k[dy][dx] * S(P - (dx, dy)) over in-image neighbours, then sqrt(v * (1/spp)). */
 __global__ __launch_bounds__(256) void k_film(const double* __restrict__ raw, int width, int height, double spp_inv,
-                                              PtFilm3 kern, PtBandMap map, double* __restrict__ out) {
-  const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= (long long)width * height) return;
+                                              PtFilm3 kern, PtBandMap map, double* __restrict__ out, int row0, int row1) {
+  const long long p = (long long)row0 * width + (long long)blockIdx.x * blockDim.x + threadIdx.x; /* rows [row0, row1) of the image */
+  if (p >= (long long)width * row1) return;
   const int x = (int)(p % width), y = (int)(p / width);
   double r = 0.0, g = 0.0, b = 0.0;
   int k = 0;

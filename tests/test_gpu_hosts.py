@@ -120,6 +120,26 @@ def test_python_integrator_mirror(P, tmp_path):
         I.Integrator.create(width=8, height=8, image=np.zeros((8, 8, 3), dtype=np.float32), samples_per_pixel=1, max_bounces=1, scene=hs)
 
 
+@pytest.mark.parametrize("slabs", [1, 2, 3, 8])
+def test_ptx_render_pipelines_the_last_accumulate_into_a_pinned_image(P, oracle, slabs, monkeypatch):
+    """ptx_render into a pinned image: the frame's last accumulate runs in PTX_FINAL_SLABS row slabs, and slab k is filmed and copied
+    to the host on a second stream while the later slabs are still being summed (the film reads one row beyond its slab, so it
+    waits for slab k + 1).  Ragged slab heights, one and several batches: the framebuffer is the plain path's bit for bit."""
+    monkeypatch.setenv("PTX_FINAL_SLABS", str(slabs))
+    w, h, depth = 700, 515, 5
+    d = oracle.desc_shirley(w, h)
+    g = P.Scene(d.ptr, 0, keepalive=d)
+    img = np.full((h, w, 3), -1.0)
+    for spp, ppb in ((3, 0), (7, 2), (4, 4)):
+        ref, _ = g.render(w, h, spp, depth, passes_per_batch=ppb)  # unpinned: staged copy, one film launch
+        g.pin_image(img)
+        img[:] = -1.0
+        g.render(w, h, spp, depth, out=img, passes_per_batch=ppb)
+        g.unpin_image()
+        assert np.array_equal(img.view(np.uint64), ref.view(np.uint64)), (spp, ppb)
+    g.close()
+
+
 def test_ptx_render_into_pinned_and_unpinned_images(P, oracle):
     """ptx_render's way back to the host: a staged copy into any image, one DMA into an image the caller has pinned
     (ptx_image_pin: the caller promises to keep it mapped until ptx_image_unpin / ptx_scene_destroy -- the library never pins

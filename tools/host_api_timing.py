@@ -20,3 +20,15 @@ for k in range(3):
     sc.render_raw_device(p, raw.data_ptr())
     torch.cuda.synchronize()
     print(f"ptx_render_raw_device call {k}: {1e3 * (time.perf_counter() - t0):.1f} ms wall")
+# the same call into an image the caller has pinned (ptx_image_pin), with the frame's tail pipelined in PTX_FINAL_SLABS row slabs
+import numpy as np
+for slabs in ("1", "2", "4", "8"):
+    os.environ["PTX_FINAL_SLABS"] = slabs
+    fb = np.zeros((h, w, 3))
+    sc.pin_image(fb)
+    sc.render(w, h, spp, depth, out=fb)
+    t0 = time.perf_counter()
+    for _ in range(5):
+        sc.render(w, h, spp, depth, out=fb)
+    print(f"ptx_render into a pinned image, PTX_FINAL_SLABS={slabs}: {1e3 * (time.perf_counter() - t0) / 5:.2f} ms")
+    sc.unpin_image()
