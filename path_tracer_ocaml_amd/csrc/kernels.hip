@@ -2416,6 +2416,7 @@ struct PtSolo {
   int32_t max_bounces;
   uint32_t cap_entries; /* capacity of each of the two queues, in entries */
 };
+#define PT_BOUNCE_POOL_ENTRY_BYTES(LDS_SCENE_) ((LDS_SCENE_) ? 6u : 8u) /* k_bounce's pool entries: 32-bit queue index + 16- / 32-bit slot */
 #ifndef PT_SOLO_ONE_BIN_CHUNKS
 #define PT_SOLO_ONE_BIN_CHUNKS 2 /* a workgroup whose input of a solo turn is at most this many chunks per wave puts all survivors into one bin */
 #endif
@@ -2488,7 +2489,11 @@ __global__ __launch_bounds__(PT_BOUNCE_THREADS, PT_BOUNCE_WAVES) void k_bounce(P
     scl.sph = sv.sph;
     scl.tri = sv.tri;
   }
-  uint2 (*pool)[128] = (uint2 (*)[128])(lds_raw + pool_off) + (size_t)wave * PT_N_SHADE_CAT;
+  /* the wave's five pools: queue indices (32 bits) and hit slots apart -- an LDS-resident scene has fewer than 65536 slots, so
+   * its slots take 16 bits: 6 bytes per entry instead of 8, 20 KB of a 1024-thread workgroup's LDS for the scene image */
+  typedef typename std::conditional<LDS_SCENE, uint16_t, uint32_t>::type PoolSlotT;
+  uint32_t (*pool_i)[128] = (uint32_t (*)[128])(lds_raw + pool_off) + (size_t)wave * PT_N_SHADE_CAT;
+  PoolSlotT (*pool_s)[128] = (PoolSlotT (*)[128])(lds_raw + pool_off + (size_t)nw * PT_N_SHADE_CAT * 128 * sizeof(uint32_t)) + (size_t)wave * PT_N_SHADE_CAT;
   uint32_t cnt[PT_N_SHADE_CAT];
 #pragma unroll
   for (int k = 0; k < PT_N_SHADE_CAT; ++k) cnt[k] = 0u;
@@ -2501,7 +2506,7 @@ __global__ __launch_bounds__(PT_BOUNCE_THREADS, PT_BOUNCE_WAVES) void k_bounce(P
    * stragglers -- three or four cut chunks -- before it could resume any, which is what held the cut at 16 rays.)  16-byte entries
    * {queue index, node | slot << 16, t}; + {u, v} for triangle hits; + {node, slot} as 32-bit words on the walk from HBM / L2. */
   const uint32_t park_cap = (uint32_t)PT_PARK_CAP(nw, CUT);
-  uint4* const park0 = (uint4*)(lds_raw + pool_off + (size_t)nw * PT_N_SHADE_CAT * 128 * sizeof(uint2));
+  uint4* const park0 = (uint4*)(lds_raw + pool_off + (size_t)nw * PT_N_SHADE_CAT * 128 * PT_BOUNCE_POOL_ENTRY_BYTES(LDS_SCENE));
   uint4* const park_uv = park0 + park_cap;
   uint4* const park_w = park_uv + (TAIL_UV ? park_cap : 0u);
   bool more = true;    /* wave-uniform: the workgroup's share of the queue is not exhausted */
@@ -2543,9 +2548,9 @@ __global__ __launch_bounds__(PT_BOUNCE_THREADS, PT_BOUNCE_WAVES) void k_bounce(P
   case K: {                                                                                                                \
     cnt[K] = start;                                                                                                        \
     if (live) {                                                                                                            \
-      const uint2 e = pool[K][start + lane];                                                                               \
-      i = e.x;                                                                                                             \
-      sl = (int)e.y;                                                                                                       \
+      i = pool_i[K][start + lane];                                                                                         \
+      sl = (int)pool_s[K][start + lane];                                                                                   \
+      if (LDS_SCENE && sl == 0xffff) sl = -1; /* (misses are filed with slot -1) */                                        \
     }                                                                                                                      \
     pt_shade_entry<EMIT, PRIMARY, K>((PT_SHADE_LDS_GEOM && LDS_SCENE) ? scl : sc, q, hits, contrib, alpha, bounce, last_bounce, g, i, live, so, ##__VA_ARGS__); \
   } break;
@@ -2663,7 +2668,11 @@ __global__ __launch_bounds__(PT_BOUNCE_THREADS, PT_BOUNCE_WAVES) void k_bounce(P
 #pragma unroll
     for (int k = 0; k < PT_N_SHADE_CAT; ++k) {
       const unsigned long long m = __ballot(cat == k);
-      if (cat == k) pool[k][cnt[k] + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = make_uint2(i, (uint32_t)r.slot);
+      if (cat == k) {
+        const uint32_t at = cnt[k] + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+        pool_i[k][at] = i;
+        pool_s[k][at] = (PoolSlotT)r.slot;
+      }
       cnt[k] += (uint32_t)__popcll(m);
     }
     if (TAIL) {
