@@ -2426,7 +2426,7 @@ struct PtSolo {
 template <int MODE, bool COUNT, bool EMIT, bool PRIMARY, bool LDS_SCENE = true, bool SOLO_T = false>
 __global__ __launch_bounds__(PT_BOUNCE_THREADS, PT_BOUNCE_WAVES) void k_bounce(PtSceneDev sc, PtQueue q, PtHits hits, PtQueue out, PtContrib contrib,
                                                                  const double* __restrict__ alpha, int bounce, int last_bounce, PtGenParams g,
-                                                                 uint32_t n_primary, int stack_depth, uint32_t pool_off, uint4* susp,
+                                                                 uint32_t n_primary, int stack_depth, uint32_t pool_off,
                                                                  PtCounters* counters, int fence_wg, PtSolo solo) {
   extern __shared__ __attribute__((aligned(64))) unsigned char lds_raw[];
   __shared__ uint32_t lds_out[PT_POOL_BINS];
@@ -2482,7 +2482,7 @@ __global__ __launch_bounds__(PT_BOUNCE_THREADS, PT_BOUNCE_WAVES) void k_bounce(P
   if (gridDim.x > 0) return; /* diagnostic build: launch + the scene image in LDS, nothing else */
 #endif
   /* the shade steps read the slots' kinds and geometry where the walk reads them: the LDS image (generic pointers: flat loads) */
-  static_assert(!PT_SHADE_LDS_GEOM || PT_LDS_SPH_DOUBLES == 4, "the shade step strides sphere records by 4 doubles");
+  static_assert(!PT_SHADE_LDS_GEOM || PT_LDS_SPH_DOUBLES == 4, "the shade step strides sphere records by 4 doubles (6: measured, no gain -- the scan's bank conflicts are not what binds)");
   PtSceneDev scl = sc;
   if (PT_SHADE_LDS_GEOM && LDS_SCENE) {
     scl.slot_kind = sv.kind;

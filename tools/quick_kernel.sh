@@ -7,9 +7,9 @@ cat > $T <<EOT
 #define PT_KERNELS_ONLY 1
 #include "$PWD/kernels.hip"
 template __global__ void k_shade_pool<false, false>(PtSceneDev, PtQueue, PtHits, PtQueue, PtContrib, const double*, int, int, PtGenParams, uint32_t, uint32_t*);
-template __global__ void k_bounce<0, false, false, false, true>(PtSceneDev, PtQueue, PtHits, PtQueue, PtContrib, const double*, int, int, PtGenParams, uint32_t, int, uint32_t, uint4*, PtCounters*, int, PtSolo);
-template __global__ void k_bounce<1, false, true, false, true>(PtSceneDev, PtQueue, PtHits, PtQueue, PtContrib, const double*, int, int, PtGenParams, uint32_t, int, uint32_t, uint4*, PtCounters*, int, PtSolo);
-template __global__ void k_bounce<1, false, false, false, false>(PtSceneDev, PtQueue, PtHits, PtQueue, PtContrib, const double*, int, int, PtGenParams, uint32_t, int, uint32_t, uint4*, PtCounters*, int, PtSolo);
+template __global__ void k_bounce<0, false, false, false, true>(PtSceneDev, PtQueue, PtHits, PtQueue, PtContrib, const double*, int, int, PtGenParams, uint32_t, int, uint32_t, PtCounters*, int, PtSolo);
+template __global__ void k_bounce<1, false, true, false, true>(PtSceneDev, PtQueue, PtHits, PtQueue, PtContrib, const double*, int, int, PtGenParams, uint32_t, int, uint32_t, PtCounters*, int, PtSolo);
+template __global__ void k_bounce<1, false, false, false, false>(PtSceneDev, PtQueue, PtHits, PtQueue, PtContrib, const double*, int, int, PtGenParams, uint32_t, int, uint32_t, PtCounters*, int, PtSolo);
 ${QK_EXTRA}
 EOT
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -std=c++17 -O3 -fPIC -ffp-contract=off -fno-fast-math -fno-math-errno --cuda-device-only -S -o ${T%.hip}.s $T \
