@@ -1,8 +1,8 @@
 #!/bin/bash
-# usage (on an MI355X box): tools/round_record.sh <tag>      e.g. r04_final
+# usage (on an MI355X box): tools/round_record.sh <tag>      e.g. r05_final
 # The end-of-round record: full GPU suite log, smoke, the driver's bench command (with its `workloads` block), every workload as its
 # own bench line, the share timings -> gpurun_out/<tag>_*  (copy what should be judged into profiles/).
-tag=${1:-r04_final}
+tag=${1:-r05_final}
 mkdir -p gpurun_out
 python -m pytest tests -m gpu -x -q > gpurun_out/${tag}_pytest_gpu.log 2>&1; echo "pytest exit $?"; tail -2 gpurun_out/${tag}_pytest_gpu.log
 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
@@ -18,6 +18,17 @@ print('headline', round(d['value'],1), 'Msamples/s', round(d['ms_per_step'],2), 
 for k, v in d.get('workloads', {}).items():
     print(' ', k, {a: (round(b, 2) if isinstance(b, float) else b) for a, b in v.items() if a in ('ms_per_step', 'value', 'dominant_kernel', 'dominant_kernel_ms_one_stream', 'error')},
           'parity', (v.get('parity') or {}).get('rel_linf_vs_cpu_ref'), 'hbm_frame', round(((v.get('hbm_frame') or {}).get('frac') or 0), 3))
+PY
+# the multi-rank line on this one GPU: two ranks sharing the device over gloo (host-staged exchange) -- timed-frame parity over both
+# ranks' bands, the CPU leg, config 5 across the ranks, the collective block
+timeout -k 10 500 python bench.py --gpus 2 --backend gloo --steps 3 --warmup 1 > gpurun_out/${tag}_bench_gloo2.json 2> gpurun_out/${tag}_bench_gloo2.err; echo "gloo-2 bench exit $?"
+python - "$tag" <<'PY'
+import json, sys
+d=json.loads([l for l in open('gpurun_out/%s_bench_gloo2.json' % sys.argv[1]) if l.startswith('{')][-1])
+w=d['workloads']['shirley_4k_spp256_d8']
+print('gloo-2 on one GPU: headline', round(d['ms_per_step'],2), 'ms, timed-frame parity', d['parity']['timed_frame']['rel_linf_vs_cpu_ref'], 'ranks covered', d['parity']['timed_frame']['ranks_covered'],
+      '; world', d['collective']['world'], 'render ms per rank', [round(x,2) for x in d['collective']['render_ms_per_rank']], 'gather', round(d['collective']['rank0_gather_ms'],2),
+      '; config 5:', round(w['ms_per_step'],1), 'ms, parity', w['parity']['rel_linf_vs_cpu_ref'], '; cpu', round(d['cpu_baseline']['value'],1))
 PY
 bash tools/bench_all.sh
 python tools/band_share_timing.py ${tag%_final} 2>/dev/null | tail -8
