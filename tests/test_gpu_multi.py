@@ -182,3 +182,31 @@ def test_peer_access_between_two_devices(P):
     if stn["peer_copies"] != n - 1:
         # the bytes are right either way (asserted above); which way they travelled is a property of the node
         pytest.xfail(f"peer access was granted for {stn['peer_copies']} of {n - 1} replicas on this node: the rest were staged through host memory")
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_bench_multi_rank_line_on_one_gpu(world):
+    """`bench.py --gpus N --backend gloo` with the N ranks sharing this one GPU (host-staged exchange): the one-process-per-GPU path
+    end to end -- self-launched ranks, band deal, queued renders, the exchange into rank 0, banded film -- and the line it prints:
+    whole pixels of the TIMED, GATHERED frame equal the oracle's to 1e-5 and come from every rank's bands, the collective block
+    says what the library saw.  (On N GPUs the backend is RCCL; that run is the driver's.)"""
+    import json
+    import sys
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--backend", "gloo", "--steps", "2", "--warmup", "1",
+                        "--workload", "shirley_600x300_spp32_d8", "--cpu-seconds", "1"], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{") and l.rstrip().endswith("}")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = lines[0]
+    assert d["n_gpus"] == world and d["value"] > 0 and d["scaling"] == "strong"
+    tf = d["parity"]["timed_frame"]
+    assert tf["rel_linf_vs_cpu_ref"] is not None and tf["rel_linf_vs_cpu_ref"] <= 1e-5, tf
+    assert tf["ranks_covered"] == list(range(world)), tf
+    assert d["parity"]["rel_linf_vs_cpu_ref"] <= 1e-5
+    col = d["collective"]
+    assert col["world"] == world and len(col["render_ms_per_rank"]) == world and all(x > 0 for x in col["render_ms_per_rank"])
+    assert col["rank0_gather_ms"] > 0 and col["rank0_film_ms"] > 0
+    assert d["cpu_baseline"]["value"] > 0
