@@ -10,8 +10,10 @@
  *              (integrator.ml:30-66), background on a miss; survivors are compacted into the next queue
  *   accum    : per-pixel radiance sums in pass order
  *   film     : 3x3 binomial reconstruction + gamma (filter_kernel.ml, film_tile.ml, integrator.ml:114-128,152-154)
- * Scenes whose tree fits LDS run trace + shade of a bounce as ONE kernel (k_bounce: a wave walks 64 rays, files them in
- * per-category pools, shades a pool when it holds 64); scenes walked from HBM / L2 keep k_trace + k_shade_pool.
+ * A render runs trace + shade of a bounce as ONE kernel (k_bounce: a wave walks 64 rays, files them in per-category pools, shades
+ * a pool when it holds 64) -- around an LDS copy of the scene where tree and packets fit one, over the per-octant node image in
+ * HBM / L2 otherwise; k_trace + k_shade_pool remain for what k_bounce does not cover (ptx_intersect_rays, scenes too large for
+ * LDS beside the pools, PTX_FUSED = 0).
  *
  * Compiled with -ffp-contract=off; every fused multiply-add below is written out exactly where the
  * reference writes Float.fma / _mm256_fmadd_pd.  No MFMA: there is no dense contraction on this path.
@@ -2338,16 +2340,16 @@ __global__ __launch_bounds__(PT_POOL_THREADS, PT_SHADE_WAVES) void k_shade_pool(
   }
 }
 
-/* ------------------------------------------------------------------ one kernel per bounce (LDS-resident scenes)
+/* ------------------------------------------------------------------ one kernel per bounce
  * k_trace and k_shade_pool of two batches share every CU so that one batch's vector-bound walk fills the other's waits for
  * memory -- but a 128-VGPR shade wave that waits two thirds of its life holds its quarter of the register file while it
  * does, and the split 4 trace + 2 shade waves per SIMD halves the shade stage's own latency hiding (the frame gained 6 % over
  * running the two kernels one after the other).  k_bounce is both stages in ONE wave: it walks a chunk of
- * 64 queued rays (pt_trace_ray, tail cut and parked walks exactly as in k_trace), files the finished rays in its
+ * 64 queued rays (pt_trace_ray with k_trace's tail cut; the walks it cuts short are pooled per workgroup in LDS), files the finished rays in its
  * per-category pools, and whenever a pool holds 64 entries shades them (pt_shade_entry, pt_pool_push exactly as in
  * k_shade_pool).  Every wave of the CU then spends most of its life walking, the waits of a wave that shades are covered by
  * the three others on its SIMD, the hit slot never goes through memory, and a bounce is one launch.  One 1024-thread
- * workgroup per CU: [stacks][scene image][16 waves x 5 pools] in LDS.  Same tests in the same order per ray, same
+ * workgroup per CU: [stacks][scene image][16 waves x 5 pools][parked walks] in LDS.  Same tests in the same order per ray, same
  * arithmetic per segment: the results are those of the two-kernel path bit for bit. */
 #ifndef PT_BOUNCE_THREADS
 #define PT_BOUNCE_THREADS 1024
