@@ -387,13 +387,30 @@ typedef unsigned int pt_u2 __attribute__((ext_vector_type(2), aligned(4)));
 #define PT_SWZ_SIGNSEL 0
 #endif
 #define PT_SWZ_LEAF 0xfffeu
+/* Layout 3: TAGGED links (round 5).  Node addresses are multiples of 4, so the two low bits of a 16-bit link are free:
+ *   tag 0  a node to visit                       tag 1  "this lane holds a leaf; afterwards continue at link & ~3"
+ *   tag 2  PT_SWZ_END: the walk is over          tag 3  "holds a leaf; afterwards the walk is over" (PT_SWZ_END | 1)
+ * A leaf's near[o] entry is its skip[o] entry with bit 0 set, so a visit ends with ONE select, `node = hit ? near[o] : skip[o]`,
+ * and the walk's whole control state is that register: wants a node step <=> (node & 3) == 0, holds a leaf <=> node & 1,
+ * finished <=> node == PT_SWZ_END.  The leaf's (first slot, real count) word stays in the register the visit loaded it into
+ * (`lkx`) until the leaf phase decodes it.  Before: a leaf compare, two conditional updates of (leaf_first, leaf_n), the END
+ * compare, the conditional update of `node` and the (walking > leaf_n) compare -- 9 of a visit's 27 vector instructions. */
+#ifndef PT_SWZ_TAGGED
+#define PT_SWZ_TAGGED 1 /* (0: the untagged links of round 4, for the A/B) */
+#endif
+#define PT_SWZ_TAG_LEAF 1u
+#define PT_SWZ_TAG_END 2u
 /* doubles per sphere slot in the LDS copy: 4 used ({x, y, z, r}) + padding.  With 4 (8 words) a slot starts in 8 of the 64 banks
  * only; with 6 (12 words) in 16.  Global memory keeps 4. */
 #ifndef PT_LDS_SPH_DOUBLES
 #define PT_LDS_SPH_DOUBLES 4
 #endif
 #define PT_SPH_STRIDE(SWZ_) ((SWZ_) ? PT_LDS_SPH_DOUBLES : 4)
+#if PT_SWZ_SIGNSEL && PT_SWZ_TAGGED
+#define PT_SWZ_END 0xfffeu /* tag 2 (see PT_SWZ_TAG_*) */
+#else
 #define PT_SWZ_END 0xffffu
+#endif
 /* bytes of LDS a wave keeps for traversal stacks: LDS-resident scenes walk the threaded image (no per-lane stack) and
  * only the camera-ray packet walk keeps its shared (node, mask) stack there: 12 bytes per level, rounded to 16 */
 #define PT_WAVE_STACK_BYTES(LDS_SCENE, StackT, depth) ((LDS_SCENE) ? (size_t)(depth) * 16u : ((std::is_same<StackT, PtThreadTag>::value || std::is_same<StackT, PtThreadOctTag>::value) ? (size_t)0 : (size_t)(depth) * PT_WAVE * sizeof(StackT)))
@@ -516,21 +533,24 @@ struct PtTraverser {
   double qa, one_over_a;
   PtTraceResult r;
   int sp;
+  /* TAGGED (the LDS image, layout 3): `node` carries the walk's control state in its two low bits (PT_SWZ_TAG_*), `walking` and
+   * `leaf_n` are not used between the leaf phases; `lkx` = word 6 of the node visited last (a leaf's first slot | real count << 16) */
+  static constexpr bool TAGGED = SWZ && (PT_SWZ_SIGNSEL != 0) && (PT_SWZ_TAGGED != 0);
   uint32_t node;
+  mutable uint32_t lkx;
   uint32_t walking; /* 0 / 1: an integer, so that "wants a node step" is ONE unsigned comparison (walking > leaf_n) */
   int leaf_first, leaf_n;
-  __device__ __forceinline__ bool wants_node() const { return walking > (uint32_t)leaf_n; }
+  __device__ __forceinline__ bool wants_node() const { return TAGGED ? (node & 3u) == 0u : walking > (uint32_t)leaf_n; }
   /* the same as a wave mask, straight from the comparison: the ballot builtin of the very expression the branch tests lets the
    * compiler use ONE v_cmp for both (HIP's __ballot of a boolean that is also branched on costs two more vector instructions
    * per turn; __builtin_amdgcn_uicmp a second compare); 38 = signed greater than, 33 = not equal */
-  __device__ __forceinline__ unsigned long long wants_node_mask() const { return __builtin_amdgcn_ballot_w64(walking > (uint32_t)leaf_n); }
-  __device__ __forceinline__ unsigned long long holds_leaf_mask() const { return __builtin_amdgcn_sicmp(leaf_n, 0, 38); }
-  __device__ __forceinline__ unsigned long long walking_mask() const { return __builtin_amdgcn_uicmp(walking, 0u, 33); }
-  __device__ __forceinline__ bool idle() const { return !walking && leaf_n == 0; }
-  __device__ __forceinline__ void park() {
-    walking = 0u;
-    leaf_n = 0;
-  }
+  __device__ __forceinline__ unsigned long long wants_node_mask() const { return __builtin_amdgcn_ballot_w64(wants_node()); }
+  __device__ __forceinline__ bool holds_leaf() const { return TAGGED ? (node & PT_SWZ_TAG_LEAF) != 0u : leaf_n > 0; }
+  __device__ __forceinline__ unsigned long long holds_leaf_mask() const { return TAGGED ? __builtin_amdgcn_ballot_w64((node & PT_SWZ_TAG_LEAF) != 0u) : __builtin_amdgcn_sicmp(leaf_n, 0, 38); }
+  /* the ray's walk is not over (it wants a node step or holds a leaf) */
+  __device__ __forceinline__ bool alive() const { return TAGGED ? node != PT_SWZ_END : (walking != 0u || leaf_n > 0); }
+  /* ... as a wave mask, where no lane holds a leaf (after the leaf phase: the chunk cut) */
+  __device__ __forceinline__ unsigned long long walking_mask() const { return TAGGED ? __builtin_amdgcn_uicmp(node, PT_SWZ_END, 33) : __builtin_amdgcn_uicmp(walking, 0u, 33); }
 
   __device__ __forceinline__ void begin(const PtSceneDev& sc, const PtSceneView& sv, V3 o_, V3 d_,
                                         unsigned long long& c_floor) {
@@ -640,6 +660,8 @@ struct PtTraverser {
     if (OCT) skip_off = dirs * sv.n_nodes;
     node = SWZ ? sv.swz_root : ((G32 && !OCT && sv.has_top) ? PT_TOP_FLAG : 0u); /* the root (slot 0 of the top image) */
     walking = sc.n_nodes > 0;
+    if (TAGGED && sc.n_nodes <= 0) node = PT_SWZ_END;
+    lkx = 0u;
     leaf_first = 0;
     leaf_n = 0;
     if (FILT) update_t32();
@@ -691,6 +713,7 @@ struct PtTraverser {
         const pt_f2 by = *(const __attribute__((address_space(3))) pt_f2*)PT_LDS_AT(nd + sel_y);
         const pt_f2 bz = *(const __attribute__((address_space(3))) pt_f2*)PT_LDS_AT(nd + sel_z);
         const pt_u2 lk = *(const __attribute__((address_space(3))) pt_u2*)PT_LDS_AT(nd + PT_SWZ_OFF_LINKS);
+        lkx = lk.x;
         na = lk.x & 0xffffu;
         nb = (lk.x >> 16) | ((lk.y & 3u) << 30);
         n_real = lk.x >> 16;
@@ -807,7 +830,10 @@ struct PtTraverser {
     constexpr bool THREAD32 = G32;
     uint32_t skip;
 #if PT_SWZ_SIGNSEL
-    if (SWZ) skip = (uint32_t)*(const __attribute__((address_space(3))) uint16_t*)PT_LDS_AT(node + skip_off + PT_SWZ_OFF_SKIP);
+    if (SWZ) {
+      skip = (uint32_t)*(const __attribute__((address_space(3))) uint16_t*)PT_LDS_AT(node + skip_off + PT_SWZ_OFF_SKIP);
+      if (TAGGED) asm("" : "+v"(skip)); /* (a zero-extended 16-bit load the select below need not mask again) */
+    }
 #else
     if (SWZ) skip = (uint32_t)*(const uint16_t*)(sv.swz_nodes + node + skip_off);
 #endif
@@ -819,11 +845,19 @@ struct PtTraverser {
 #if PT_SWZ_NEAR
     if (SWZ) {
 #if PT_SWZ_SIGNSEL
-      const uint32_t near_c = (uint32_t)*(const __attribute__((address_space(3))) uint16_t*)PT_LDS_AT(node + skip_off + PT_SWZ_OFF_NEAR);
+      uint32_t near_c = (uint32_t)*(const __attribute__((address_space(3))) uint16_t*)PT_LDS_AT(node + skip_off + PT_SWZ_OFF_NEAR);
+      if (TAGGED) asm("" : "+v"(near_c));
 #else
       const uint32_t near_c = (uint32_t)*(const uint16_t*)(sv.swz_nodes + node + skip_off + 16u);
 #endif
       const bool hit = test_box(sv, node, na, nb, n_real);
+      if (TAGGED) {
+        /* an inner node that was hit: its near child; a leaf that was hit: what follows it, tagged "holds a leaf"; a miss: what
+         * follows this subtree (PT_SWZ_END: nothing) */
+        if (COUNT && PT_DIAG == 0 && hit && (near_c & PT_SWZ_TAG_LEAF)) c_prims += (unsigned long long)(MODE == PT_MODE_SIMD ? ((n_real + 3u) & ~3u) : n_real);
+        node = hit ? near_c : skip;
+        return;
+      }
       const bool leaf_hit = hit && near_c == PT_SWZ_LEAF;
       if (leaf_hit) {
         leaf_first = (int)na;
@@ -878,6 +912,11 @@ struct PtTraverser {
   /* Leaf.intersect on the held leaf (caller checks leaf_n > 0) */
   __device__ __forceinline__ void packet(const PtSceneView& sv, unsigned long long& c_nodes, unsigned long long& c_floor) {
     const double t_min = 0.0;
+    if (TAGGED) { /* the leaf's word, as the visit that took it loaded it */
+      leaf_first = (int)(lkx & 0xffffu);
+      leaf_n = (int)(lkx >> 16);
+      node &= ~PT_SWZ_TAG_LEAF; /* -> the node that follows the leaf, or PT_SWZ_END */
+    }
     if (MODE == PT_MODE_SIMD) {
       /* spheres_intersect_aux, lib.rs:102-178, one packet lane per step, split in two so the wave stays
        * dense: SCAN (cheap, every lane: f, c, b', discriminant) runs until the lane meets a slot whose
@@ -1070,7 +1109,7 @@ __device__ __forceinline__ PtTraceResult pt_trace_ray(const PtSceneDev& sc, cons
     tr.r.slot = tc->slot;
     if (tr.FILT) tr.update_t32(); /* the filter's copy of t: stale, it would pass boxes beyond the restored hit */
   }
-  while (valid && (tr.walking || tr.leaf_n > 0)) {
+  while (valid && tr.alive()) {
     /* DIV_LOOP: the node walk as ONE divergent loop: a lane stays in it while it wants node steps, so the lanes still walking
      * are simply the loop's exec mask (no per-turn ballot of a `want` flag, no `continue`, no exit-reason bookkeeping: the
      * first version of this loop spent ~19 of its ~80 instructions per turn on that).  Same rule as below: once fewer than
@@ -1080,12 +1119,18 @@ __device__ __forceinline__ PtTraceResult pt_trace_ray(const PtSceneDev& sc, cons
     if constexpr (DIV_LOOP) {
      if (tr.wants_node()) {
       bool leaf_waiting = false; /* wave-uniform: a lane of this wave left the walk holding a leaf */
+      /* TAGGED: "a lane has left the walk" instead (scalar: the loop's exec mask against the one it was entered with) -- a lane
+       * leaves with a leaf or because its walk is over; when the few that are left come out and no leaf is waiting, the chunk cut
+       * below looks at them a little earlier than it used to.  A change of schedule only: which tests a ray performs is its own affair */
+      const unsigned long long entered = tr.TAGGED ? __builtin_amdgcn_ballot_w64(true) : 0ull;
       for (;;) {
         if (COUNT && PT_DIAG == 1 && !ORIGIN_ZERO) PT_DIAG_WAVE_SLOTS(c_floor);
         tr.node_step(sv, stack, c_nodes, c_prims);
-        if (__ballot(tr.leaf_n > 0) != 0) leaf_waiting = true;
+        if (!tr.TAGGED && __ballot(tr.leaf_n > 0) != 0) leaf_waiting = true;
         if (!tr.wants_node()) break;
-        if (leaf_waiting && pt_popc_mask(__builtin_amdgcn_ballot_w64(true)) < WALK_MIN) break;
+        const unsigned long long now = __builtin_amdgcn_ballot_w64(true);
+        if (tr.TAGGED) leaf_waiting = now != entered;
+        if (leaf_waiting && pt_popc_mask(now) < WALK_MIN) break;
       }
      }
     } else {
@@ -1103,17 +1148,17 @@ __device__ __forceinline__ PtTraceResult pt_trace_ray(const PtSceneDev& sc, cons
     if (COUNT && PT_DIAG == 6 && !ORIGIN_ZERO) { /* (diagnostic build: ticks the wave spends in the leaf phase, into c_prims; lane 0's copy is kept) */
       __builtin_amdgcn_sched_barrier(0);
       const unsigned long long t0_ = __builtin_readcyclecounter();
-      if (tr.leaf_n > 0) tr.packet(sv, c_nodes, c_floor);
+      if (tr.holds_leaf()) tr.packet(sv, c_nodes, c_floor);
       __builtin_amdgcn_sched_barrier(0);
       c_prims += __builtin_readcyclecounter() - t0_;
     } else
-    if (tr.leaf_n > 0) tr.packet(sv, c_nodes, c_floor);
+    if (tr.holds_leaf()) tr.packet(sv, c_nodes, c_floor);
     /* nobody holds a leaf here: a safe place to stop.  The ballot sees the rays that are still walking (finished
      * lanes have left the loop), and every one of them sees the same count. */
     if (tc && pt_popc_mask(tr.walking_mask()) < tc->min_active) break;
   }
   if (tc) {
-    tc->unfinished = valid && tr.walking;
+    tc->unfinished = valid && tr.alive(); /* (no lane holds a leaf here) */
     tc->node = tr.node;
   }
   if (COUNT && c_filter) {
@@ -1142,7 +1187,7 @@ __device__ __forceinline__ PtTraceResult pt_trace_packet(const PtSceneDev& sc, c
   PtTraverser<MODE, COUNT, ORIGIN_ZERO, uint32_t, SWZ> tr;
   unsigned long long no_count = 0; /* lanes without a sample run begin() on a dummy ray: keep them out of the counters */
   tr.begin(sc, sv, valid ? o : v3(0.0, 0.0, 0.0), valid ? d : v3(0.0, 0.0, -1.0), valid ? c_floor : no_count);
-  unsigned long long remaining = __ballot(valid && tr.walking);
+  unsigned long long remaining = __ballot(valid && tr.alive());
   while (remaining != 0) {
     /* the lanes that share the first remaining lane's direction signs */
     const uint32_t d0 = (uint32_t)__builtin_amdgcn_readlane((int)tr.dirs, __ffsll((long long)remaining) - 1);
@@ -1219,6 +1264,7 @@ __device__ __forceinline__ PtTraceResult pt_trace_packet(const PtSceneDev& sc, c
           } else if (hit) {
             tr.leaf_first = (int)ua;
             tr.leaf_n = (int)n_real;
+            tr.lkx = ua | (n_real << 16); /* (TAGGED: packet() decodes the leaf's word itself) */
             tr.packet(sv, c_nodes, c_floor);
           }
         } else {
@@ -1336,7 +1382,12 @@ __device__ __forceinline__ PtSceneView pt_scene_view(const PtSceneDev& sc, unsig
         sk[o] = nx == 0xffffu ? (uint16_t)PT_SWZ_END : (uint16_t)(nbase + nx * PT_SWZ_NODE_BYTES);
 #if PT_SWZ_NEAR
         uint16_t* nr = (uint16_t*)((unsigned char*)w + PT_SWZ_OFF_NEAR);
+#if PT_SWZ_SIGNSEL && PT_SWZ_TAGGED
+        /* tagged links (PT_SWZ_TAG_*): a leaf's entry is what follows it, with "holds a leaf" set */
+        nr[o] = leaf ? (uint16_t)(sk[o] | PT_SWZ_TAG_LEAF) : (uint16_t)(nbase + (((o >> axis) & 1) ? src->a : (src->b & 0x3fffffffu)) * PT_SWZ_NODE_BYTES);
+#else
         nr[o] = leaf ? (uint16_t)PT_SWZ_LEAF : (uint16_t)(nbase + (((o >> axis) & 1) ? src->a : (src->b & 0x3fffffffu)) * PT_SWZ_NODE_BYTES);
+#endif
 #endif
       }
     }
