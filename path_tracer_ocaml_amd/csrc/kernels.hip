@@ -506,6 +506,23 @@ __device__ __forceinline__ uint32_t pt_stack_pop(const PtThreadOctTag*, int) { r
 #ifndef PT_DIAG_EXTRA_LOADS
 #define PT_DIAG_EXTRA_LOADS 0
 #endif
+/* diagnostic builds only (tools/README.md, "what binds the node loop"): PT_DIAG_VISIT_VALU = n more vector instructions per
+ * visit of the LDS walk, PT_DIAG_VISIT_LDS = n more 16-bit LDS reads (+ one vector add each), PT_DIAG_VISIT_SALU = n more scalar ones */
+#ifndef PT_DIAG_VISIT_VALU
+#define PT_DIAG_VISIT_VALU 0
+#endif
+#ifndef PT_DIAG_VISIT_LDS
+#define PT_DIAG_VISIT_LDS 0
+#endif
+#ifndef PT_DIAG_VISIT_SALU
+#define PT_DIAG_VISIT_SALU 0
+#endif
+#ifndef PT_WALK_ASM
+#define PT_WALK_ASM 1 /* k_bounce on LDS scenes: the node loop in assembly (PtTraverser::walk_asm); 0: the compiler's loop */
+#endif
+#ifndef PT_SCAN_ADDC
+#define PT_SCAN_ADDC 1
+#endif
 #ifndef PT_PACKET_DEFER
 #define PT_PACKET_DEFER 1
 #endif
@@ -538,6 +555,7 @@ struct PtTraverser {
   static constexpr bool TAGGED = SWZ && (PT_SWZ_SIGNSEL != 0) && (PT_SWZ_TAGGED != 0);
   uint32_t node;
   mutable uint32_t lkx;
+  uint32_t lkx_diag = 0u, sdiag = 0u; /* (PT_DIAG_VISIT_*) */
   uint32_t walking; /* 0 / 1: an integer, so that "wants a node step" is ONE unsigned comparison (walking > leaf_n) */
   int leaf_first, leaf_n;
   __device__ __forceinline__ bool wants_node() const { return TAGGED ? (node & 3u) == 0u : walking > (uint32_t)leaf_n; }
@@ -672,6 +690,90 @@ struct PtTraverser {
     c2 = c2base + (t32 < 0x1p120f ? t32 * PT_MARGIN_T : 0.0f);
   }
 
+#if PT_WALK_ASM
+  /* The node loop of the LDS walk (TAGGED), written out in gfx950 assembly.  Measured (tools/README.md "what binds the node
+   * loop", profiles/r05_visit_sensitivity.txt): three more vector instructions per visit cost the headline frame 0.5 %, six more
+   * SCALAR ones 1.6 % -- with four waves per SIMD, each issuing at most one instruction per turn, the walk is bound by the number
+   * of instructions a wave issues per visit, of whatever kind, and of the compiler's 56 (21 vector + 6 LDS + 4 waits + ~25 scalar
+   * of exec-mask algebra for a loop with a divergent and a uniform exit and a divergent branch inside) the scalar ones are
+   * bookkeeping.  Here a visit is 21 vector + 6 LDS + 4 waits + 6 ... 9 scalar instructions: the exec mask IS the set of lanes
+   * that still want a node step, a lane leaves by one s_and of exec, and the filter's undecided case is a wave-uniform exit.
+   * Same loads, same arithmetic, same select as node_step (read the two side by side).
+   * Runs visits until no lane wants one, or -- once a lane has left -- fewer than `wmin` are still walking.  Returns nonzero if it
+   * stopped BEFORE the select of a visit because the binary32 filter left a lane undecided: the caller performs that visit with
+   * node_step (the binary64 arithmetic lives there) and calls again.  Temporaries live in v120..v127 (the halves of a
+   * ds_read2_b32 result cannot be named through an operand): 128-VGPR kernels only (k_bounce). */
+  __device__ __forceinline__ unsigned long long walk_asm(int wmin) {
+    register uint32_t bx0 asm("v120"), bx1 asm("v121"), by0 asm("v122"), by1 asm("v123"), bz0 asm("v124"), bz1 asm("v125"), lk0 asm("v126"), lk1 asm("v127");
+    lk0 = lkx;
+    unsigned long long und, sv_, ent_, hit_;
+    uint32_t a_, sk_, nr_, tg_, n_;
+    float tn_, tf_, p_, q_, r_, s_, m2_;
+    asm volatile(
+        "s_mov_b64 %[sv], exec\n"
+        "s_mov_b64 %[und], 0\n"
+        "v_and_b32 %[tg], 3, %[node]\n"
+        "v_cmp_eq_u32 vcc, 0, %[tg]\n"
+        "s_and_b64 exec, exec, vcc\n"
+        "s_cbranch_execz .Ldone%=\n"
+        "s_mov_b64 %[ent], exec\n"
+        "s_waitcnt lgkmcnt(0)\n" /* (scalar loads return out of order: nothing of the compiler's may be outstanding) */
+        ".Lloop%=:\n"
+        "v_add_u32 %[a], %[node], %[so]\n"
+        "ds_read_u16 %[sk], %[a] offset:44\n"
+        "ds_read_u16 %[nr], %[a] offset:60\n"
+        "v_add_u32 %[a], %[node], %[sx]\n"
+        "ds_read2_b32 v[120:121], %[a] offset1:1\n"
+        "v_add_u32 %[a], %[node], %[sy]\n"
+        "ds_read2_b32 v[122:123], %[a] offset1:1\n"
+        "v_add_u32 %[a], %[node], %[sz]\n"
+        "ds_read2_b32 v[124:125], %[a] offset1:1\n"
+        "ds_read2_b32 v[126:127], %[node] offset0:9 offset1:10\n"
+        "s_waitcnt lgkmcnt(3)\n"
+        "v_fma_f32 %[tn], %[bx0], %[fix], %[fnx]\n"
+        "v_fma_f32 %[tf], %[bx1], %[fix], %[fnx]\n"
+        "s_waitcnt lgkmcnt(2)\n"
+        "v_fma_f32 %[p], %[by0], %[fiy], %[fny]\n"
+        "v_fma_f32 %[q], %[by1], %[fiy], %[fny]\n"
+        "s_waitcnt lgkmcnt(1)\n"
+        "v_fma_f32 %[r], %[bz0], %[fiz], %[fnz]\n"
+        "v_fma_f32 %[s], %[bz1], %[fiz], %[fnz]\n"
+        "v_max_f32 %[tn], %[tn], %[p]\n"
+        "v_min_f32 %[tf], %[tf], %[q]\n"
+        "v_max3_f32 %[tn], %[tn], %[r], 0\n"
+        "v_min3_f32 %[tf], %[tf], %[s], %[t32]\n"
+        "s_waitcnt lgkmcnt(0)\n"
+        "v_fma_f32 %[m2], %[lk1], %[k2], %[c2]\n"
+        "v_sub_f32 %[tf], %[tf], %[tn]\n"
+        "v_cmp_ge_f32_e64 %[hit], %[tf], %[m2]\n"
+        "v_cmp_nge_f32_e64 vcc, |%[tf]|, %[m2]\n"
+        "s_cbranch_vccnz .Lund%=\n"
+        "v_cndmask_b32_e64 %[node], %[sk], %[nr], %[hit]\n"
+        "v_and_b32 %[tg], 3, %[node]\n"
+        "v_cmp_eq_u32 vcc, 0, %[tg]\n"
+        "s_and_b64 exec, exec, vcc\n"
+        "s_cbranch_execz .Ldone%=\n"
+        "s_cmp_eq_u64 exec, %[ent]\n"
+        "s_cbranch_scc1 .Lloop%=\n"
+        "s_bcnt1_i32_b64 %[n], exec\n"
+        "s_cmp_ge_u32 %[n], %[wmin]\n"
+        "s_cbranch_scc1 .Lloop%=\n"
+        "s_branch .Ldone%=\n"
+        ".Lund%=:\n"
+        "s_mov_b64 %[und], vcc\n"
+        ".Ldone%=:\n"
+        "s_mov_b64 exec, %[sv]\n"
+        : [node] "+v"(node), [lk0] "+v"(lk0), [lk1] "=&v"(lk1), [bx0] "=&v"(bx0), [bx1] "=&v"(bx1), [by0] "=&v"(by0), [by1] "=&v"(by1),
+          [bz0] "=&v"(bz0), [bz1] "=&v"(bz1), [und] "=&s"(und), [sv] "=&s"(sv_), [ent] "=&s"(ent_), [hit] "=&s"(hit_), [n] "=&s"(n_),
+          [a] "=&v"(a_), [sk] "=&v"(sk_), [nr] "=&v"(nr_), [tg] "=&v"(tg_), [tn] "=&v"(tn_), [tf] "=&v"(tf_), [p] "=&v"(p_), [q] "=&v"(q_),
+          [r] "=&v"(r_), [s] "=&v"(s_), [m2] "=&v"(m2_)
+        : [so] "v"(skip_off), [sx] "v"(sel_x), [sy] "v"(sel_y), [sz] "v"(sel_z), [fix] "v"(fix), [fiy] "v"(fiy), [fiz] "v"(fiz), [fnx] "v"(fnx),
+          [fny] "v"(fny), [fnz] "v"(fnz), [t32] "v"(t32), [k2] "v"(k2), [c2] "v"(c2), [wmin] "s"(wmin)
+        : "vcc", "scc");
+    lkx = lk0;
+    return und;
+  }
+#endif
   /* Visit `node`: bbox test against the closest hit so far, then descend / hold the leaf / pop.  The traversal
    * stack (far children only) lives in LDS, one column per lane (conflict-free ds_write / ds_read).  A far child's
    * bbox is tested when it is POPPED, against the closest hit so far -- exactly the t_max the reference's recursion
@@ -852,6 +954,11 @@ struct PtTraverser {
 #endif
       const bool hit = test_box(sv, node, na, nb, n_real);
       if (TAGGED) {
+#if PT_DIAG_VISIT_VALU || PT_DIAG_VISIT_LDS || PT_DIAG_VISIT_SALU
+        for (int k_ = 0; k_ < PT_DIAG_VISIT_VALU; ++k_) asm volatile("v_add_u32 %0, 1, %0" : "+v"(lkx_diag));
+        for (int k_ = 0; k_ < PT_DIAG_VISIT_LDS; ++k_) lkx_diag += (uint32_t)*(const __attribute__((address_space(3))) uint16_t*)PT_LDS_AT(node + skip_off + PT_SWZ_OFF_SKIP + 2u * (uint32_t)(k_ + 1));
+        for (int k_ = 0; k_ < PT_DIAG_VISIT_SALU; ++k_) { uint32_t t_; asm volatile("s_mov_b32 %0, 1" : "=s"(t_)); }
+#endif
         /* an inner node that was hit: its near child; a leaf that was hit: what follows it, tagged "holds a leaf"; a miss: what
          * follows this subtree (PT_SWZ_END: nothing) */
         if (COUNT && PT_DIAG == 0 && hit && (near_c & PT_SWZ_TAG_LEAF)) c_prims += (unsigned long long)(MODE == PT_MODE_SIMD ? ((n_real + 3u) & ~3u) : n_real);
@@ -942,8 +1049,22 @@ struct PtTraverser {
           const double wy = pt_fma(d.y, bp_over_a, -fy);
           const double wz = pt_fma(d.z, bp_over_a, -fz);
           const double disc = (s[3] * s[3]) - pt_fma(wx, wx, pt_fma(wy, wy, wz * wz));
+#if PT_SCAN_ADDC
+          /* "neither NaN nor sign bit set" (lib.rs:162-166) is ONE unsigned comparison of the bit pattern (+0 ... +inf), and the
+           * candidate mask takes the outcome as the carry of cand + cand: two vector instructions instead of five; the mask
+           * comes out in reverse order and is turned round once per leaf */
+          {
+            const unsigned long long fm = __builtin_amdgcn_ballot_w64((unsigned long long)__double_as_longlong(disc) <= 0x7ff0000000000000ull);
+            unsigned long long co_;
+            asm("v_addc_co_u32_e64 %0, %1, %0, %0, %2" : "+v"(cand), "=s"(co_) : "s"(fm));
+          }
+#else
           if ((disc == disc) && !pt_signbit(disc)) cand |= 1u << k;
+#endif
         }
+#if PT_SCAN_ADDC
+        cand = __brev(cand) >> (32 - m); /* slot k -> bit k (m >= 1) */
+#endif
         while (cand != 0) {
           if (COUNT && PT_DIAG == 4 && !ORIGIN_ZERO) {
             c_nodes++;
@@ -1090,7 +1211,7 @@ struct PtTailCtl {
   int slot;
   bool unfinished;  /* out: the ray is still walking */
 };
-template <int MODE, bool COUNT, bool ORIGIN_ZERO, typename StackT, bool SWZ = false, bool DIV_LOOP = (PT_WALK_LOOP != 0)>
+template <int MODE, bool COUNT, bool ORIGIN_ZERO, typename StackT, bool SWZ = false, bool DIV_LOOP = (PT_WALK_LOOP != 0), bool ASM_WALK = false>
 __device__ __forceinline__ PtTraceResult pt_trace_ray(const PtSceneDev& sc, const PtSceneView& sv, StackT* stack,
                                                       V3 o, V3 d, unsigned long long& c_nodes,
                                                       unsigned long long& c_prims, unsigned long long& c_floor,
@@ -1116,7 +1237,13 @@ __device__ __forceinline__ PtTraceResult pt_trace_ray(const PtSceneDev& sc, cons
      * PT_WALK_MIN lanes are walking and some lane holds a leaf, the pending packets are intersected first.  Half the SCALAR
      * instructions per turn: +3 % time in k_trace at 8 waves per SIMD (scalar issue is not what binds there), -1 % in k_bounce
      * at 4 (with half the waves, a wave busy with scalar bookkeeping is more often the one the vector pipe is waiting for). */
-    if constexpr (DIV_LOOP) {
+    if constexpr (ASM_WALK && (PT_WALK_ASM != 0) && (PT_DIAG == 0) && !COUNT && PtTraverser<MODE, COUNT, ORIGIN_ZERO, StackT, SWZ>::TAGGED) {
+#if PT_WALK_ASM
+      /* the node loop in assembly; a visit the binary32 filter cannot decide for some lane is performed here, in binary64 */
+      while (tr.walk_asm(WALK_MIN) != 0ull)
+        if (tr.wants_node()) tr.node_step(sv, stack, c_nodes, c_prims);
+#endif
+    } else if constexpr (DIV_LOOP) {
      if (tr.wants_node()) {
       bool leaf_waiting = false; /* wave-uniform: a lane of this wave left the walk holding a leaf */
       /* TAGGED: "a lane has left the walk" instead (scalar: the loop's exec mask against the one it was entered with) -- a lane
@@ -1165,6 +1292,9 @@ __device__ __forceinline__ PtTraceResult pt_trace_ray(const PtSceneDev& sc, cons
     c_filter[0] += tr.n_undecided;
     c_filter[1] += tr.n_wave_fallbacks;
   }
+#if PT_DIAG_VISIT_VALU || PT_DIAG_VISIT_LDS || PT_DIAG_VISIT_SALU
+  if (tr.lkx_diag + tr.sdiag == 0xfffffff3u) tr.r.t = 0.0; /* (keeps the diagnostic's loads alive) */
+#endif
   return tr.r;
 }
 
@@ -2704,7 +2834,7 @@ __global__ __launch_bounds__(PT_BOUNCE_THREADS, PT_BOUNCE_WAVES) void k_bounce(P
     PT_TM5(c_floor);
     unsigned long long dg_n = 0, dg_p = 0, dg_f = 0; /* (diagnostic builds: the packet walk's own counters go nowhere) */
     if constexpr (PRIMARY && LDS_SCENE) r = pt_trace_packet<MODE, COUNT, true, true>(sc, sv, (uint32_t*)stack, valid, o, d, DIAG_T ? dg_n : c_nodes, DIAG_T ? dg_p : c_prims, DIAG_T ? dg_f : c_floor, DIAG_T ? nullptr : c_filter);
-    else r = pt_trace_ray<MODE, COUNT, PRIMARY, StackT, LDS_SCENE, LDS_SCENE ? PT_BOUNCE_DIV_LOOP(MODE) : PT_TRACE_DIV_LOOP(false)>(sc, sv, stack, o, d, c_nodes, c_prims, c_floor, valid, TAIL ? &tc : nullptr, DIAG_T ? nullptr : c_filter);
+    else r = pt_trace_ray<MODE, COUNT, PRIMARY, StackT, LDS_SCENE, LDS_SCENE ? PT_BOUNCE_DIV_LOOP(MODE) : PT_TRACE_DIV_LOOP(false), LDS_SCENE && !COUNT && MODE == PT_MODE_SIMD /* (Array_leaf kernels have no registers to pin: cornell +0.5 %) */>(sc, sv, stack, o, d, c_nodes, c_prims, c_floor, valid, TAIL ? &tc : nullptr, DIAG_T ? nullptr : c_filter);
     PT_TM5(c_nodes);
     if (DIAG_T) c_filter[1] += (lane == 0);
     const bool park = TAIL && tc.unfinished;
