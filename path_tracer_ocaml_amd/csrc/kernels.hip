@@ -2139,7 +2139,7 @@ __device__ __forceinline__ void pt_shade_entry(const PtSceneDev& sc, const PtQue
       V3 o, d, attn0, emit0 = v3(0.0, 0.0, 0.0);
       if (PRIMARY) {
         o = v3(0.0, 0.0, 0.0);
-        d = pt_primary_dir(sc, g, ps, alpha);
+        d = pt_primary_dir(sc, g, ps, alpha); /* (handed over by the walk as a 32-byte {t, direction} record instead: headline +-0, cornell +2 %, mesh +3 %: profiles/r05_ab_primary_dir.txt) */
         attn0 = v3(1.0, 1.0, 1.0); /* Color.white, integrator.ml:68 */
         id = ps.id;
         offset = ps.offset;
