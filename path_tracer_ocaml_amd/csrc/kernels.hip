@@ -429,6 +429,24 @@ struct PtThreadTag {};
 struct PtThreadOctTag {};
 #define PT_OCT_LEAF_FIRST_BITS 22
 #define PT_OCT_LEAF_REAL_MAX 255u
+/* Round 5, second layout of the per-octant record (PT_OCT_TAGGED): what the tagged links did for the LDS image, for the walk from
+ * HBM / L2 -- where four fifths of the visits are answered by the L1 in ~120 clocks and the ~45 vector + ~40 scalar instructions
+ * the old record cost per visit were as long a chain as the load.  An octant fixes the sign of every direction component, so
+ *   words 0..2  the NEAR bound of each axis for this octant (mn where the direction component is >= 0, else mx), words 3..5 the
+ *               FAR one: t_near = fma(near, inv, n), t_far = fma(far, inv, n) -- the six min / max per visit are gone (an fma with
+ *               fixed second and third operand is monotone in the first: the same bits);
+ *   word 6      what a HIT leads to: an inner node -> its near child for this octant (an index < 2^30: tag 00 in the top bits);
+ *               a leaf -> 01 << 30 | real slots << 22 | first slot: "this lane holds a leaf", the leaf's packet in the same word;
+ *   word 7      what a MISS -- or the end of the leaf -- leads to: the octant's skip link, or PT_OCT_END (1 << 31: nothing).
+ * A visit ends with one select, node = hit ? word 6 : word 7, and the walk's control state is that register: wants a node step
+ * <=> node < 2^30, holds a leaf <=> node >> 30 == 1, over <=> node >= 2^31; after the leaf phase the walk continues at the word 7
+ * the leaf's visit loaded (oct_skip).  The node's magnitude for the filter's margin comes from the bounds themselves (three
+ * v_max3 with |.| modifiers); its 1.000001 lives in the ray's k2. */
+#ifndef PT_OCT_TAGGED
+#define PT_OCT_TAGGED 1 /* must match the host's image builder (ptx_api.inc); 0: the record of round 4 */
+#endif
+#define PT_OCT_END 0x80000000u
+#define PT_OCT_LEAF_TAG 0x40000000u
 
 struct PtSceneView {
   const PtNode* nodes;
@@ -545,6 +563,7 @@ struct PtTraverser {
   float fix, fiy, fiz, fnx, fny, fnz, k2, c2base, c2, t32;
   uint32_t skip_off; /* SWZ: byte offset of this ray's octant entry in a node's skip table; OCT: index of the octant's node 0 */
   mutable uint32_t oct_skip; /* OCT: the visited node's skip link, out of its record (test_box) */
+  mutable uint32_t oct_link; /* OTAG: word 6 of the visited node's record (what a hit leads to) */
   uint32_t sel_x, sel_y, sel_z; /* PT_SWZ_SIGNSEL: byte offsets of the ray's (near, far) bound pairs */
   mutable unsigned long long n_undecided = 0, n_wave_fallbacks = 0; /* COUNT only (ptx_stats.filter_*) */
   double qa, one_over_a;
@@ -553,22 +572,24 @@ struct PtTraverser {
   /* TAGGED (the LDS image, layout 3): `node` carries the walk's control state in its two low bits (PT_SWZ_TAG_*), `walking` and
    * `leaf_n` are not used between the leaf phases; `lkx` = word 6 of the node visited last (a leaf's first slot | real count << 16) */
   static constexpr bool TAGGED = SWZ && (PT_SWZ_SIGNSEL != 0) && (PT_SWZ_TAGGED != 0);
+  static constexpr bool OTAG = OCT && (PT_OCT_TAGGED != 0); /* the per-octant record with tagged links (PT_OCT_TAGGED) */
+  static constexpr bool TAGS = TAGGED || OTAG;
   uint32_t node;
   mutable uint32_t lkx;
   uint32_t lkx_diag = 0u, sdiag = 0u; /* (PT_DIAG_VISIT_*) */
   uint32_t walking; /* 0 / 1: an integer, so that "wants a node step" is ONE unsigned comparison (walking > leaf_n) */
   int leaf_first, leaf_n;
-  __device__ __forceinline__ bool wants_node() const { return TAGGED ? (node & 3u) == 0u : walking > (uint32_t)leaf_n; }
+  __device__ __forceinline__ bool wants_node() const { return OTAG ? node < PT_OCT_LEAF_TAG : (TAGGED ? (node & 3u) == 0u : walking > (uint32_t)leaf_n); }
   /* the same as a wave mask, straight from the comparison: the ballot builtin of the very expression the branch tests lets the
    * compiler use ONE v_cmp for both (HIP's __ballot of a boolean that is also branched on costs two more vector instructions
    * per turn; __builtin_amdgcn_uicmp a second compare); 38 = signed greater than, 33 = not equal */
   __device__ __forceinline__ unsigned long long wants_node_mask() const { return __builtin_amdgcn_ballot_w64(wants_node()); }
-  __device__ __forceinline__ bool holds_leaf() const { return TAGGED ? (node & PT_SWZ_TAG_LEAF) != 0u : leaf_n > 0; }
-  __device__ __forceinline__ unsigned long long holds_leaf_mask() const { return TAGGED ? __builtin_amdgcn_ballot_w64((node & PT_SWZ_TAG_LEAF) != 0u) : __builtin_amdgcn_sicmp(leaf_n, 0, 38); }
+  __device__ __forceinline__ bool holds_leaf() const { return OTAG ? (node >> 30) == 1u : (TAGGED ? (node & PT_SWZ_TAG_LEAF) != 0u : leaf_n > 0); }
+  __device__ __forceinline__ unsigned long long holds_leaf_mask() const { return TAGS ? __builtin_amdgcn_ballot_w64(holds_leaf()) : __builtin_amdgcn_sicmp(leaf_n, 0, 38); }
   /* the ray's walk is not over (it wants a node step or holds a leaf) */
-  __device__ __forceinline__ bool alive() const { return TAGGED ? node != PT_SWZ_END : (walking != 0u || leaf_n > 0); }
+  __device__ __forceinline__ bool alive() const { return OTAG ? node < PT_OCT_END : (TAGGED ? node != PT_SWZ_END : (walking != 0u || leaf_n > 0)); }
   /* ... as a wave mask, where no lane holds a leaf (after the leaf phase: the chunk cut) */
-  __device__ __forceinline__ unsigned long long walking_mask() const { return TAGGED ? __builtin_amdgcn_uicmp(node, PT_SWZ_END, 33) : __builtin_amdgcn_uicmp(walking, 0u, 33); }
+  __device__ __forceinline__ unsigned long long walking_mask() const { return TAGS ? __builtin_amdgcn_ballot_w64(alive()) : __builtin_amdgcn_uicmp(walking, 0u, 33); }
 
   __device__ __forceinline__ void begin(const PtSceneDev& sc, const PtSceneView& sv, V3 o_, V3 d_,
                                         unsigned long long& c_floor) {
@@ -632,6 +653,7 @@ struct PtTraverser {
       fnz = ORIGIN_ZERO ? 0.0f : -(float)(o.z * inv.z);
 #endif
       k2 = fimax * PT_MARGIN_K2;
+      if (OTAG) k2 *= 1.000002f; /* (the node's magnitude is taken from its bounds as they are: test_box) */
       c2base = __builtin_fmaf(fomax * 1.000001f, k2, 1e-30f);
       /* exact_slab folded into the margin: with m2 = NaN neither `u >= m2` nor `u < -m2` holds, so every test of such a ray
        * is undecided and takes the binary64 code -- no per-visit instruction for the flag itself */
@@ -679,6 +701,7 @@ struct PtTraverser {
     node = SWZ ? sv.swz_root : ((G32 && !OCT && sv.has_top) ? PT_TOP_FLAG : 0u); /* the root (slot 0 of the top image) */
     walking = sc.n_nodes > 0;
     if (TAGGED && sc.n_nodes <= 0) node = PT_SWZ_END;
+    if (OTAG && sc.n_nodes <= 0) node = PT_OCT_END;
     lkx = 0u;
     leaf_first = 0;
     leaf_n = 0;
@@ -809,6 +832,34 @@ struct PtTraverser {
     if (FILT) {
       uint4 w0, w1;
       float mag;
+      if (OTAG) { /* nd is the node's index; the octant's tagged record (PT_OCT_TAGGED): near xyz, far xyz, hit link, miss link */
+        const uint4* p = (const uint4*)(sv.nodes32o + (size_t)(skip_off + nd) * 32u);
+        const uint4 r0 = p[0], r1 = p[1];
+        oct_link = r1.z;
+        oct_skip = r1.w;
+        n_real = (r1.z >> PT_OCT_LEAF_FIRST_BITS) & PT_OCT_LEAF_REAL_MAX; /* (meaningful for a leaf; na / nb are not used by this walk) */
+        na = r1.z & ((1u << PT_OCT_LEAF_FIRST_BITS) - 1u);
+        nb = 0u;
+        const float nx_ = __uint_as_float(r0.x), ny_ = __uint_as_float(r0.y), nz_ = __uint_as_float(r0.z);
+        const float fx_ = __uint_as_float(r0.w), fy_ = __uint_as_float(r1.x), fz_ = __uint_as_float(r1.y);
+        const float tnx = __builtin_fmaf(nx_, fix, fnx), tny = __builtin_fmaf(ny_, fiy, fny), tnz = __builtin_fmaf(nz_, fiz, fnz);
+        const float tfx = __builtin_fmaf(fx_, fix, fnx), tfy = __builtin_fmaf(fy_, fiy, fny), tfz = __builtin_fmaf(fz_, fiz, fnz);
+        const float a = __builtin_fmaxf(__builtin_fmaxf(tnx, tny), tnz);
+        const float b = __builtin_fminf(__builtin_fminf(tfx, tfy), tfz);
+        const float u = __builtin_fminf(b, t32) - __builtin_fmaxf(a, 0.0f);
+        const float mg = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(nx_), __builtin_fabsf(ny_)), __builtin_fabsf(nz_)),
+                                         __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(fx_), __builtin_fabsf(fy_)), __builtin_fabsf(fz_)));
+        const float m2 = __builtin_fmaf(mg, k2, c2);
+        hit = u >= m2;
+        if (active && !(__builtin_fabsf(u) >= m2)) { /* (as below: one divergent branch; a ray the filter does not apply to carries m2 = NaN) */
+          if (COUNT) {
+            n_undecided++;
+            if (pt_lane() == __ffsll((long long)__ballot(1)) - 1) n_wave_fallbacks++;
+          }
+          hit = slab64(sv.nodes + nd);
+        }
+        return hit;
+      }
 #if PT_SWZ_SIGNSEL
       if (SWZ) { /* nd is the node's absolute LDS address; the ray's sign-selected (near, far) bounds: see the layout */
         const pt_f2 bx = *(const __attribute__((address_space(3))) pt_f2*)PT_LDS_AT(nd + sel_x);
@@ -928,6 +979,12 @@ struct PtTraverser {
     if (COUNT && (PT_DIAG == 0 || (PT_DIAG <= 2 && !ORIGIN_ZERO))) c_nodes++;
     bool descend = false;
     uint32_t na, nb, n_real;
+    if (OTAG) { /* the tagged per-octant record: a hit leads to word 6 (near child, or "holds a leaf"), a miss to word 7 */
+      const bool hit = test_box(sv, node, na, nb, n_real);
+      if (COUNT && PT_DIAG == 0 && hit && (oct_link >> 30) == 1u) c_prims += (unsigned long long)(MODE == PT_MODE_SIMD ? ((n_real + 3u) & ~3u) : n_real);
+      node = hit ? oct_link : oct_skip;
+      return;
+    }
     /* threaded image: where to go once this subtree is done (issued beside the node's own reads) */
     constexpr bool THREAD32 = G32;
     uint32_t skip;
@@ -1023,6 +1080,11 @@ struct PtTraverser {
       leaf_first = (int)(lkx & 0xffffu);
       leaf_n = (int)(lkx >> 16);
       node &= ~PT_SWZ_TAG_LEAF; /* -> the node that follows the leaf, or PT_SWZ_END */
+    }
+    if (OTAG) { /* `node` IS the leaf's word; the walk goes on where the leaf's miss link points */
+      leaf_first = (int)(node & ((1u << PT_OCT_LEAF_FIRST_BITS) - 1u));
+      leaf_n = (int)((node >> PT_OCT_LEAF_FIRST_BITS) & PT_OCT_LEAF_REAL_MAX);
+      node = oct_skip;
     }
     if (MODE == PT_MODE_SIMD) {
       /* spheres_intersect_aux, lib.rs:102-178, one packet lane per step, split in two so the wave stays
@@ -1249,14 +1311,14 @@ __device__ __forceinline__ PtTraceResult pt_trace_ray(const PtSceneDev& sc, cons
       /* TAGGED: "a lane has left the walk" instead (scalar: the loop's exec mask against the one it was entered with) -- a lane
        * leaves with a leaf or because its walk is over; when the few that are left come out and no leaf is waiting, the chunk cut
        * below looks at them a little earlier than it used to.  A change of schedule only: which tests a ray performs is its own affair */
-      const unsigned long long entered = tr.TAGGED ? __builtin_amdgcn_ballot_w64(true) : 0ull;
+      const unsigned long long entered = tr.TAGS ? __builtin_amdgcn_ballot_w64(true) : 0ull;
       for (;;) {
         if (COUNT && PT_DIAG == 1 && !ORIGIN_ZERO) PT_DIAG_WAVE_SLOTS(c_floor);
         tr.node_step(sv, stack, c_nodes, c_prims);
-        if (!tr.TAGGED && __ballot(tr.leaf_n > 0) != 0) leaf_waiting = true;
+        if (!tr.TAGS && __ballot(tr.leaf_n > 0) != 0) leaf_waiting = true;
         if (!tr.wants_node()) break;
         const unsigned long long now = __builtin_amdgcn_ballot_w64(true);
-        if (tr.TAGGED) leaf_waiting = now != entered;
+        if (tr.TAGS) leaf_waiting = now != entered;
         if (leaf_waiting && pt_popc_mask(now) < WALK_MIN) break;
       }
      }
