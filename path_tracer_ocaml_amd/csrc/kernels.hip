@@ -2896,7 +2896,7 @@ __global__ __launch_bounds__(PT_BOUNCE_THREADS, PT_BOUNCE_WAVES) void k_bounce(P
     PT_TM5(c_floor);
     unsigned long long dg_n = 0, dg_p = 0, dg_f = 0; /* (diagnostic builds: the packet walk's own counters go nowhere) */
     if constexpr (PRIMARY && LDS_SCENE) r = pt_trace_packet<MODE, COUNT, true, true>(sc, sv, (uint32_t*)stack, valid, o, d, DIAG_T ? dg_n : c_nodes, DIAG_T ? dg_p : c_prims, DIAG_T ? dg_f : c_floor, DIAG_T ? nullptr : c_filter);
-    else r = pt_trace_ray<MODE, COUNT, PRIMARY, StackT, LDS_SCENE, LDS_SCENE ? PT_BOUNCE_DIV_LOOP(MODE) : PT_TRACE_DIV_LOOP(false), LDS_SCENE && !COUNT && MODE == PT_MODE_SIMD /* (Array_leaf kernels have no registers to pin: cornell +0.5 %) */>(sc, sv, stack, o, d, c_nodes, c_prims, c_floor, valid, TAIL ? &tc : nullptr, DIAG_T ? nullptr : c_filter);
+    else r = pt_trace_ray<MODE, COUNT, PRIMARY, StackT, LDS_SCENE, LDS_SCENE ? PT_BOUNCE_DIV_LOOP(MODE) : PT_TRACE_DIV_LOOP(false), LDS_SCENE && !COUNT && MODE == PT_MODE_SIMD /* (Array_leaf kernels have no registers to pin: cornell +0.5 %; the walk from HBM / L2 in assembly: +1.9 %, profiles/r05_ab_oct_asm.txt) */>(sc, sv, stack, o, d, c_nodes, c_prims, c_floor, valid, TAIL ? &tc : nullptr, DIAG_T ? nullptr : c_filter);
     PT_TM5(c_nodes);
     if (DIAG_T) c_filter[1] += (lane == 0);
     const bool park = TAIL && tc.unfinished;
