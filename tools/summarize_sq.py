@@ -192,23 +192,41 @@ if tr:
         tot = sum(e["one_stream"]["total_ms"] for e in ks)
         if tot > 0:
             entry[f"valu_busy_{stage}_time_weighted"] = sum(e["valu_busy"] * e["one_stream"]["total_ms"] for e in ks) / tot
-    # frame-level HBM traffic: every timed (non-COUNT) kernel's counter bytes x launches, per rendered frame.  Frames in
-    # the profiled command = k_accum launches / accumulate launches of one step (bench line: kernel_launches_per_step)
+    # frame-level HBM traffic: every timed (non-COUNT) kernel's counter bytes x launches, per rendered frame.
+    # Frames in the profiled command are counted by the walk kernels themselves: launches of the timed camera-ray (PRIMARY)
+    # instantiations / batches per frame (bench line: the walk kernel's launches per step / max_bounces).  Until round 5 the
+    # count was "k_accum launches / accumulate launches of one step" -- which stopped being a frame count when ptx_render began
+    # to issue a frame's last accumulate in four row slabs (5 launches instead of 2): 34 launches read as 17 frames where the
+    # bounce kernels had rendered 10, and the bounce stage's bytes per step came out 1.7 x too low (hbm_frame 0.23 for 0.38).
+    # k_accum and k_film run for every frame, counting render included: their totals are divided by ALL camera-ray launches.
     try:
         bl = json.loads(line[-1]) if line else {}
-        acc_per_step = bl.get("kernel_launches_per_step", {}).get("accum")
-        acc_total = out["kernels"].get("k_accum", {}).get("launches")
-        if acc_per_step and acc_total:
-            frames = acc_total / acc_per_step
+        lps = bl.get("kernel_launches_per_step", {})
+        walk_per_step = lps.get("bounce") or lps.get("trace")
+        depth = (bl.get("config") or {}).get("max_bounces")
+        def walk(k):
+            return k.startswith(("k_trace<", "k_trace_stream<", "k_bounce<"))
+        prim_timed = sum(e["launches"] for k, e in out["kernels"].items() if walk(k) and is_primary(k) and is_timed_trace(k) and e.get("launches"))
+        prim_all = sum(e["launches"] for k, e in out["kernels"].items() if walk(k) and is_primary(k) and e.get("launches"))
+        if walk_per_step and depth and prim_timed:
+            batches = walk_per_step / depth
+            frames = prim_timed / batches
+            frames_all = prim_all / batches
             def timed(k):
-                if k.startswith(("k_trace<", "k_trace_stream<", "k_bounce<")):
+                if walk(k):
                     return is_timed_trace(k)
-                return k.startswith(("k_shade", "k_accum", "k_film", "k_classify"))
-            tot = sum(e.get("hbm_bytes_per_launch", 0.0) * e["launches"] for k, e in out["kernels"].items() if timed(k) and e.get("launches"))
+                return k.startswith(("k_shade", "k_classify"))
+            def every_frame(k):
+                return k.startswith(("k_accum", "k_film"))
+            def per_step(k, e):
+                b = e.get("hbm_bytes_per_launch", 0.0) * e["launches"]
+                return b / frames if timed(k) else (b / frames_all if every_frame(k) else 0.0)
             entry["frames_profiled"] = frames
-            entry["hbm_bytes_per_step"] = tot / frames
+            entry["frames_profiled_incl_counting"] = frames_all
+            entry["frames_from"] = "camera-ray launches of the timed walk kernels / batches per frame"
+            entry["hbm_bytes_per_step"] = sum(per_step(k, e) for k, e in out["kernels"].items() if e.get("launches"))
             entry["hbm_bytes_per_step_by_stage"] = {
-                st: sum(e.get("hbm_bytes_per_launch", 0.0) * e["launches"] for k, e in out["kernels"].items() if timed(k) and k.startswith(pref) and e.get("launches")) / frames
+                st: sum(per_step(k, e) for k, e in out["kernels"].items() if k.startswith(pref) and e.get("launches"))
                 for st, pref in (("bounce", ("k_bounce",)), ("trace", ("k_trace",)), ("shade", ("k_shade", "k_classify")), ("accum", ("k_accum",)), ("film", ("k_film",)))}
     except Exception as ex:  # a profile without the bench line still summarises
         entry["hbm_bytes_per_step_error"] = str(ex)
