@@ -826,8 +826,7 @@ struct PtTraverser {
     return (tnx - lx >= m2 && hx - tfx >= m2) || (tny - ly >= m2 && hy - tfy >= m2) || (tnz - lz >= m2 && hz - tfz >= m2);
   }
   /* Bbox.is_hit of `nd` against the closest hit so far + the node's links (a, b, real slot count) */
-  __device__ __forceinline__ bool test_box(const PtSceneView& sv, uint32_t nd, uint32_t& na, uint32_t& nb, uint32_t& n_real, bool active = true,
-                                           const uint32_t* uni_lk = nullptr /* layout 3: words 6, 7 of the node if the caller holds them */) const {
+  __device__ __forceinline__ bool test_box(const PtSceneView& sv, uint32_t nd, uint32_t& na, uint32_t& nb, uint32_t& n_real, bool active = true) const {
     const double t_min = 0.0;
     bool hit;
     if (FILT) {
@@ -866,11 +865,7 @@ struct PtTraverser {
         const pt_f2 bx = *(const __attribute__((address_space(3))) pt_f2*)PT_LDS_AT(nd + sel_x);
         const pt_f2 by = *(const __attribute__((address_space(3))) pt_f2*)PT_LDS_AT(nd + sel_y);
         const pt_f2 bz = *(const __attribute__((address_space(3))) pt_f2*)PT_LDS_AT(nd + sel_z);
-        /* the node's leaf word and magnitude: the lane's own read, or the copy the packet walk already holds for the whole wave
-         * (pt_trace_packet reads the two words once per visit; reading them again per lane was one LDS instruction per visit) */
-        pt_u2 lk;
-        if (uni_lk) { lk.x = uni_lk[0]; lk.y = uni_lk[1]; }
-        else lk = *(const __attribute__((address_space(3))) pt_u2*)PT_LDS_AT(nd + PT_SWZ_OFF_LINKS);
+        const pt_u2 lk = *(const __attribute__((address_space(3))) pt_u2*)PT_LDS_AT(nd + PT_SWZ_OFF_LINKS);
         lkx = lk.x;
         na = lk.x & 0xffffu;
         nb = (lk.x >> 16) | ((lk.y & 3u) << 30);
@@ -1365,6 +1360,10 @@ __device__ __forceinline__ PtTraceResult pt_trace_ray(const PtSceneDev& sc, cons
   return tr.r;
 }
 
+/* (Round 5, measured and not kept -- profiles/r05_ab_packet_stack.txt: the shared stack below held in the LANES of three registers,
+ * v_writelane on a push and v_readlane on a pop instead of the LDS round trip behind a fence and a wave barrier: bit-exact, and
+ * +1.5 % on the headline and on cornell -- the camera rays' launches are bound by vector issue (0.85 busy) and the LDS pipe they
+ * leave idle carried the stack for nothing; the node's words 6 / 7 handed to the lanes' box test instead of read again per lane: +-0.) */
 /* Camera rays: the 64 rays of a wave are one 8x8 pixel tile of one pass, so they walk the tree TOGETHER -- one
  * shared stack of (node, lane mask) instead of 64 private ones.  A ray's own sequence of box tests and packet tests
  * is exactly pt_trace_ray's: its child order depends only on the signs of its direction (shape_tree.ml:201,209), the
@@ -1375,23 +1374,12 @@ __device__ __forceinline__ PtTraceResult pt_trace_ray(const PtSceneDev& sc, cons
 #ifndef PT_PRIMARY_PACKET
 #define PT_PRIMARY_PACKET 1
 #endif
-#ifndef PT_PACKET_LANE_STACK
-#define PT_PACKET_LANE_STACK 0 /* (1 once measured and through the suite) the packet walk's shared stack in the lanes of three registers (trees of depth <= 63); 0: in LDS */
-#endif
-#ifndef PT_PACKET_UNI_LK
-#define PT_PACKET_UNI_LK 0 /* (1 once measured and through the suite) the packet walk hands the node's words 6, 7 it read for the wave to the lanes' box test; 0: each lane reads them again */
-#endif
 template <int MODE, bool COUNT, bool ORIGIN_ZERO, bool SWZ>
 __device__ __forceinline__ PtTraceResult pt_trace_packet(const PtSceneDev& sc, const PtSceneView& sv, uint32_t* wstack,
                                                          bool valid, V3 o, V3 d, unsigned long long& c_nodes,
                                                          unsigned long long& c_prims, unsigned long long& c_floor,
-                                                         unsigned long long* c_filter = nullptr, bool lane_stack = false) {
+                                                         unsigned long long* c_filter = nullptr) {
   const int lane = pt_lane();
-  /* PT_PACKET_LANE_STACK: the shared (far child, lane mask) stack in the LANES of three registers -- level L lives in lane L, the
-   * stack pointer is wave-uniform, so a push is three v_writelane and a pop three v_readlane: no LDS round trip, no fence and no
-   * wave barrier per pop (the LDS stack: lane 0 writes, then ds_read + s_waitcnt + readfirstlane x 3 behind a fence).  64 levels:
-   * the caller asks for it only when the tree is no deeper (lane_stack, wave-uniform); else the LDS stack. */
-  uint32_t st_node = 0u, st_lo = 0u, st_hi = 0u;
   PtTraverser<MODE, COUNT, ORIGIN_ZERO, uint32_t, SWZ> tr;
   unsigned long long no_count = 0; /* lanes without a sample run begin() on a dummy ray: keep them out of the counters */
   tr.begin(sc, sv, valid ? o : v3(0.0, 0.0, 0.0), valid ? d : v3(0.0, 0.0, -1.0), valid ? c_floor : no_count);
@@ -1407,14 +1395,11 @@ __device__ __forceinline__ PtTraceResult pt_trace_packet(const PtSceneDev& sc, c
     for (;;) {
       /* the node's links: one address for the whole wave */
       uint32_t ua, ub, n_real;
-      uint32_t pk_lk[2] = {0u, 0u}; /* layout 3: the node's words 6, 7, wave-uniform (handed to the lanes' box test) */
       if (SWZ) { /* node = byte offset in the binary32 image */
 #if PT_SWZ_SIGNSEL
         const pt_u2 lk = *(const __attribute__((address_space(3))) pt_u2*)PT_LDS_AT(node + PT_SWZ_OFF_LINKS);
         const uint32_t w6 = (uint32_t)__builtin_amdgcn_readfirstlane((int)lk.x);
         const uint32_t w7 = (uint32_t)__builtin_amdgcn_readfirstlane((int)lk.y);
-        pk_lk[0] = w6;
-        pk_lk[1] = w7;
 #else
         const unsigned char* nbase = sv.swz_nodes + node;
         const uint32_t w6 = (uint32_t)__builtin_amdgcn_readfirstlane((int)*(const uint32_t*)(nbase + PT_SWZ_OFF_LINKS));
@@ -1433,10 +1418,6 @@ __device__ __forceinline__ PtTraceResult pt_trace_packet(const PtSceneDev& sc, c
       if (act) {
         if (COUNT) c_nodes++;
         uint32_t x0, x1, x2;
-#if PT_SWZ_SIGNSEL
-        if (SWZ && PT_PACKET_UNI_LK) hit = tr.test_box(sv, node, x0, x1, x2, true, pk_lk);
-        else
-#endif
         hit = tr.test_box(sv, node, x0, x1, x2);
       }
       const unsigned long long hm = __ballot(hit);
@@ -1485,21 +1466,7 @@ __device__ __forceinline__ PtTraceResult pt_trace_packet(const PtSceneDev& sc, c
         } else {
           const uint32_t lhs = ua, rhs = ub & 0x3fffffffu;
           const bool lhs_first = (d0 >> axis) & 1u;
-          if (PT_PACKET_LANE_STACK && lane_stack) {
-            /* (no writelane builtin in this clang; a VOP3 instruction reads one SGPR on gfx9, so the lane select travels in m0 -- a
-             * RESERVED register: a clobber would be ignored, the compiler may count on its value, so it is saved and put back here) */
-            const uint32_t far_c = lhs_first ? rhs : lhs, hm_lo = (uint32_t)hm, hm_hi = (uint32_t)(hm >> 32);
-            uint32_t m0_keep;
-            asm volatile("s_mov_b32 %3, m0\n"
-                         "s_mov_b32 m0, %4\n"
-                         "s_nop 1\n"
-                         "v_writelane_b32 %0, %5, m0\n"
-                         "v_writelane_b32 %1, %6, m0\n"
-                         "v_writelane_b32 %2, %7, m0\n"
-                         "s_mov_b32 m0, %3\n"
-                         : "+v"(st_node), "+v"(st_lo), "+v"(st_hi), "=&s"(m0_keep)
-                         : "s"(sp), "s"(far_c), "s"(hm_lo), "s"(hm_hi));
-          } else if (lane == 0) {
+          if (lane == 0) {
             wstack[3 * sp] = lhs_first ? rhs : lhs;
             wstack[3 * sp + 1] = (uint32_t)hm;
             wstack[3 * sp + 2] = (uint32_t)(hm >> 32);
@@ -1513,17 +1480,11 @@ __device__ __forceinline__ PtTraceResult pt_trace_packet(const PtSceneDev& sc, c
       if (!descended) {
         if (sp == 0) break;
         --sp;
-        unsigned long long pm;
-        if (PT_PACKET_LANE_STACK && lane_stack) {
-          node = (uint32_t)__builtin_amdgcn_readlane((int)st_node, sp);
-          pm = (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)st_lo, sp) | ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)st_hi, sp) << 32);
-        } else {
-          __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-          __builtin_amdgcn_wave_barrier();
-          node = (uint32_t)__builtin_amdgcn_readfirstlane((int)wstack[3 * sp]);
-          pm = (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)wstack[3 * sp + 1]) |
-               ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)wstack[3 * sp + 2]) << 32);
-        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        node = (uint32_t)__builtin_amdgcn_readfirstlane((int)wstack[3 * sp]);
+        const unsigned long long pm = (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)wstack[3 * sp + 1]) |
+                                      ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)wstack[3 * sp + 2]) << 32);
         act = (pm >> lane) & 1ull;
       }
     }
@@ -1824,7 +1785,7 @@ __global__ __launch_bounds__(PT_TRACE_BLOCK_OF(MODE, LDS_SCENE), (LDS_SCENE && M
         }
       }
       if (COUNT && valid) c_seg++;
-      const PtTraceResult r = pt_trace_packet<MODE, COUNT, PRIMARY, LDS_SCENE>(sc, sv, wstack, valid, o, d, c_nodes, c_prims, c_floor, c_filter, stack_depth <= 63);
+      const PtTraceResult r = pt_trace_packet<MODE, COUNT, PRIMARY, LDS_SCENE>(sc, sv, wstack, valid, o, d, c_nodes, c_prims, c_floor, c_filter);
       if (valid) {
         pt_hit_store(hits, i, r.t, r.slot, r.u, r.v, MODE == PT_MODE_ARRAY && sc.has_triangles);
       }
@@ -2649,8 +2610,10 @@ __global__ __launch_bounds__(PT_POOL_THREADS, PT_SHADE_WAVES) void k_shade_pool(
 #define PT_BOUNCE_WAVES 4 /* waves per SIMD asked of the register allocator (PT_BOUNCE_THREADS / 256); 768 threads / 3 waves: +16 % */
 #endif
 #ifndef PT_BOUNCE_DIV_LOOP
-#define PT_BOUNCE_DIV_LOOP(MODE) ((MODE) == PT_MODE_SIMD) /* the walk phase's node loop as one divergent loop (pt_trace_ray DIV_LOOP):
-                                                              headline -0.7 ... -1.1 %, cornell (Array_leaf) +1 % */
+#define PT_BOUNCE_DIV_LOOP(MODE) ((MODE) == PT_MODE_SIMD || (PT_SWZ_SIGNSEL && PT_SWZ_TAGGED)) /* the walk phase's node loop as one divergent
+                                                              loop (pt_trace_ray DIV_LOOP): headline -0.7 ... -1.1 %; cornell (Array_leaf) +1 % with
+                                                              the untagged links of round 4, -1.5 % with tagged ones (no ballot of "a lane holds a
+                                                              leaf" per turn any more: profiles/r05_ab_divloop_array_and_global_thresholds.txt) */
 #endif
 #ifndef PT_BOUNCE_MIN_CHUNKS
 #define PT_BOUNCE_MIN_CHUNKS 2 /* chunks per wave below which fewer workgroups take part (k_shade_pool: 16 -- there a chunk is a few microseconds) */
@@ -2938,7 +2901,7 @@ __global__ __launch_bounds__(PT_BOUNCE_THREADS, PT_BOUNCE_WAVES) void k_bounce(P
     PtTraceResult r;
     PT_TM5(c_floor);
     unsigned long long dg_n = 0, dg_p = 0, dg_f = 0; /* (diagnostic builds: the packet walk's own counters go nowhere) */
-    if constexpr (PRIMARY && LDS_SCENE) r = pt_trace_packet<MODE, COUNT, true, true>(sc, sv, (uint32_t*)stack, valid, o, d, DIAG_T ? dg_n : c_nodes, DIAG_T ? dg_p : c_prims, DIAG_T ? dg_f : c_floor, DIAG_T ? nullptr : c_filter, stack_depth <= 63);
+    if constexpr (PRIMARY && LDS_SCENE) r = pt_trace_packet<MODE, COUNT, true, true>(sc, sv, (uint32_t*)stack, valid, o, d, DIAG_T ? dg_n : c_nodes, DIAG_T ? dg_p : c_prims, DIAG_T ? dg_f : c_floor, DIAG_T ? nullptr : c_filter);
     else r = pt_trace_ray<MODE, COUNT, PRIMARY, StackT, LDS_SCENE, LDS_SCENE ? PT_BOUNCE_DIV_LOOP(MODE) : PT_TRACE_DIV_LOOP(false), LDS_SCENE && !COUNT && MODE == PT_MODE_SIMD /* (Array_leaf kernels have no registers to pin: cornell +0.5 %; the walk from HBM / L2 in assembly: +1.9 %, profiles/r05_ab_oct_asm.txt) */>(sc, sv, stack, o, d, c_nodes, c_prims, c_floor, valid, TAIL ? &tc : nullptr, DIAG_T ? nullptr : c_filter);
     PT_TM5(c_nodes);
     if (DIAG_T) c_filter[1] += (lane == 0);
