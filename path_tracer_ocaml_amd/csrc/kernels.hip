@@ -445,6 +445,11 @@ struct PtThreadOctTag {};
 #ifndef PT_OCT_TAGGED
 #define PT_OCT_TAGGED 1 /* must match the host's image builder (ptx_api.inc); 0: the record of round 4 */
 #endif
+#ifndef PT_OCT_PREOFFSET
+#define PT_OCT_PREOFFSET 0 /* (with PT_OCT_TAGGED; must match the host builder) 1: the links of octant o's records are record numbers in the whole image
+                              (o * n_nodes + k) and so is the walk's `node`: a visit's address is ONE multiply-add instead of add, shift, add at the
+                              head of its chain; the binary64 fallback subtracts the octant's base again */
+#endif
 #define PT_OCT_END 0x80000000u
 #define PT_OCT_LEAF_TAG 0x40000000u
 
@@ -701,6 +706,7 @@ struct PtTraverser {
     node = SWZ ? sv.swz_root : ((G32 && !OCT && sv.has_top) ? PT_TOP_FLAG : 0u); /* the root (slot 0 of the top image) */
     walking = sc.n_nodes > 0;
     if (TAGGED && sc.n_nodes <= 0) node = PT_SWZ_END;
+    if (OTAG && PT_OCT_PREOFFSET) node = skip_off; /* the root's record of this ray's octant */
     if (OTAG && sc.n_nodes <= 0) node = PT_OCT_END;
     lkx = 0u;
     leaf_first = 0;
@@ -833,7 +839,10 @@ struct PtTraverser {
       uint4 w0, w1;
       float mag;
       if (OTAG) { /* nd is the node's index; the octant's tagged record (PT_OCT_TAGGED): near xyz, far xyz, hit link, miss link */
-        const uint4* p = (const uint4*)(sv.nodes32o + (size_t)(skip_off + nd) * 32u);
+        /* PT_OCT_PREOFFSET: nd is the record's number in the whole image; the image is smaller than 4 GiB (the host builds it only then),
+         * so the byte offset is a 32-bit shift and the load takes it beside the scalar base: one instruction ahead of the loads */
+        const uint4* p = PT_OCT_PREOFFSET ? (const uint4*)(sv.nodes32o + (uint32_t)(nd << 5))
+                                          : (const uint4*)(sv.nodes32o + (size_t)(skip_off + nd) * 32u);
         const uint4 r0 = p[0], r1 = p[1];
         oct_link = r1.z;
         oct_skip = r1.w;
@@ -856,7 +865,7 @@ struct PtTraverser {
             n_undecided++;
             if (pt_lane() == __ffsll((long long)__ballot(1)) - 1) n_wave_fallbacks++;
           }
-          hit = slab64(sv.nodes + nd);
+          hit = slab64(sv.nodes + (PT_OCT_PREOFFSET ? nd - skip_off : nd)); /* (the canonical node: the octant's base off again) */
         }
         return hit;
       }
