@@ -446,7 +446,7 @@ struct PtThreadOctTag {};
 #define PT_OCT_TAGGED 1 /* must match the host's image builder (ptx_api.inc); 0: the record of round 4 */
 #endif
 #ifndef PT_OCT_PREOFFSET
-#define PT_OCT_PREOFFSET 0 /* (with PT_OCT_TAGGED; must match the host builder) 1: the links of octant o's records are record numbers in the whole image
+#define PT_OCT_PREOFFSET 1 /* (with PT_OCT_TAGGED; must match the host builder; 0: links are node indices, as in the first tagged record) the links of octant o's records are record numbers in the whole image
                               (o * n_nodes + k) and so is the walk's `node`: a visit's address is ONE multiply-add instead of add, shift, add at the
                               head of its chain; the binary64 fallback subtracts the octant's base again */
 #endif
