@@ -445,6 +445,10 @@ struct PtThreadOctTag {};
 #ifndef PT_OCT_TAGGED
 #define PT_OCT_TAGGED 1 /* must match the host's image builder (ptx_api.inc); 0: the record of round 4 */
 #endif
+#ifndef PT_FILTER_DEBUG
+#define PT_FILTER_DEBUG 0 /* diagnostic builds only (tools/filter_error_study.py): the traverser keeps the u and the margin of its last box test on the
+                             per-octant record, and the library gains ptx_debug_filter_error -- not in the product build */
+#endif
 #ifndef PT_OCT_PREOFFSET
 #define PT_OCT_PREOFFSET 1 /* (with PT_OCT_TAGGED; must match the host builder; 0: links are node indices, as in the first tagged record) the links of octant o's records are record numbers in the whole image
                               (o * n_nodes + k) and so is the walk's `node`: a visit's address is ONE multiply-add instead of add, shift, add at the
@@ -569,6 +573,9 @@ struct PtTraverser {
   uint32_t skip_off; /* SWZ: byte offset of this ray's octant entry in a node's skip table; OCT: index of the octant's node 0 */
   mutable uint32_t oct_skip; /* OCT: the visited node's skip link, out of its record (test_box) */
   mutable uint32_t oct_link; /* OTAG: word 6 of the visited node's record (what a hit leads to) */
+#if PT_FILTER_DEBUG
+  mutable float dbg_u, dbg_m2; /* the binary32 filter's u = hi~ - lo~ and margin m2 of the last box test (OTAG branch) */
+#endif
   uint32_t sel_x, sel_y, sel_z; /* PT_SWZ_SIGNSEL: byte offsets of the ray's (near, far) bound pairs */
   mutable unsigned long long n_undecided = 0, n_wave_fallbacks = 0; /* COUNT only (ptx_stats.filter_*) */
   double qa, one_over_a;
@@ -859,6 +866,10 @@ struct PtTraverser {
         const float mg = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(nx_), __builtin_fabsf(ny_)), __builtin_fabsf(nz_)),
                                          __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(fx_), __builtin_fabsf(fy_)), __builtin_fabsf(fz_)));
         const float m2 = __builtin_fmaf(mg, k2, c2);
+#if PT_FILTER_DEBUG
+        dbg_u = u;
+        dbg_m2 = m2;
+#endif
         hit = u >= m2;
         if (active && !(__builtin_fabsf(u) >= m2)) { /* (as below: one divergent branch; a ray the filter does not apply to carries m2 = NaN) */
           if (COUNT) {
@@ -3149,6 +3160,47 @@ __global__ void k_load_rays(long long n, const double* __restrict__ o, const dou
   if (i >= n) return;
   pt_q_store_ray(q, (uint32_t)i, v3(o[3 * i], o[3 * i + 1], o[3 * i + 2]), v3(d[3 * i], d[3 * i + 1], d[3 * i + 2]));
 }
+
+#if PT_FILTER_DEBUG
+/* Diagnostic builds only: the PRODUCTION box test of the walk from HBM / L2 (PtTraverser::begin + test_box on the tagged per-octant
+ * record) on a list of (ray, node, closest hit so far) triples, and beside it the reference's binary64 quantities of the same test
+ * (Bbox.is_hit, bbox.ml:40-56, the arithmetic of pt_slab_hit_fast: finite 1 / d only).  out[6 i ..] = u32, m2, lo64, hi64,
+ * the filter's outcome (1 hit / 0 miss decided, -1 undecided), the outcome test_box returns (its fallback included). */
+__global__ __launch_bounds__(256) void k_filter_error(PtSceneDev sc, long long n, const double* __restrict__ o3, const double* __restrict__ d3,
+                                                      const int32_t* __restrict__ nodes, const double* __restrict__ tmax, double* __restrict__ out) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  PtSceneView sv;
+  sv.nodes = sc.nodes; sv.skip32 = sc.node_skip32; sv.nodes32 = (const unsigned char*)sc.nodes32; sv.nodes32o = (const unsigned char*)sc.nodes32o;
+  sv.n_nodes = (uint32_t)sc.n_nodes; sv.swz_nodes = nullptr; sv.swz_root = 0u; sv.top = nullptr; sv.has_top = false; sv.sph = sc.sph; sv.tri = sc.tri;
+  sv.kind = sc.slot_kind; sv.cat = sc.slot_cat; sv.nodes64 = nullptr; sv.floor_lds = nullptr; sv.n_floor_lds = 0;
+  PtSceneDev scn = sc;
+  scn.n_floor = 0; /* (no floor pre-test: the closest hit so far is the caller's) */
+  const V3 o = v3(o3[3 * i], o3[3 * i + 1], o3[3 * i + 2]), d = v3(d3[3 * i], d3[3 * i + 1], d3[3 * i + 2]);
+  PtTraverser<PT_MODE_ARRAY, false, false, PtThreadOctTag, false> tr;
+  unsigned long long cf = 0;
+  tr.begin(scn, sv, o, d, cf);
+  tr.r.t = tmax[i];
+  tr.update_t32();
+  const uint32_t k = (uint32_t)nodes[i];
+  uint32_t na, nb, nr;
+  const bool final_hit = tr.test_box(sv, PT_OCT_PREOFFSET ? tr.skip_off + k : k, na, nb, nr);
+  const float u = tr.dbg_u, m2 = tr.dbg_m2;
+  const PtNode* np = sc.nodes + k;
+  const V3 inv = v3(1.0 / d.x, 1.0 / d.y, 1.0 / d.z);
+  const double t0x = (np->mn[0] - o.x) * inv.x, t0y = (np->mn[1] - o.y) * inv.y, t0z = (np->mn[2] - o.z) * inv.z;
+  const double t1x = (np->mx[0] - o.x) * inv.x, t1y = (np->mx[1] - o.y) * inv.y, t1z = (np->mx[2] - o.z) * inv.z;
+  const double a = __builtin_fmax(__builtin_fmin(t0x, t1x), __builtin_fmax(__builtin_fmin(t0y, t1y), __builtin_fmin(t0z, t1z)));
+  const double b = __builtin_fmin(__builtin_fmax(t0x, t1x), __builtin_fmin(__builtin_fmax(t0y, t1y), __builtin_fmax(t0z, t1z)));
+  double* r = out + 6 * i;
+  r[0] = (double)u;
+  r[1] = (double)m2;
+  r[2] = __builtin_fmax(0.0, a);
+  r[3] = __builtin_fmin(tmax[i], b);
+  r[4] = (__builtin_fabsf(u) >= m2) ? (u >= m2 ? 1.0 : 0.0) : -1.0;
+  r[5] = final_hit ? 1.0 : 0.0;
+}
+#endif
 
 #ifndef PT_KERNELS_ONLY /* (tools/quick_kernel.sh instantiates single kernels of this file for register / ISA studies) */
 #include "bvh_build_gpu.inc"
