@@ -429,7 +429,7 @@ struct PtThreadTag {};
 struct PtThreadOctTag {};
 #define PT_OCT_LEAF_FIRST_BITS 22
 #define PT_OCT_LEAF_REAL_MAX 255u
-/* Round 5, second layout of the per-octant record (PT_OCT_TAGGED): what the tagged links did for the LDS image, for the walk from
+/* Round 5, second layout of the per-octant record: what the tagged links did for the LDS image, for the walk from
  * HBM / L2 -- where four fifths of the visits are answered by the L1 in ~120 clocks and the ~45 vector + ~40 scalar instructions
  * the old record cost per visit were as long a chain as the load.  An octant fixes the sign of every direction component, so
  *   words 0..2  the NEAR bound of each axis for this octant (mn where the direction component is >= 0, else mx), words 3..5 the
@@ -442,18 +442,16 @@ struct PtThreadOctTag {};
  * <=> node < 2^30, holds a leaf <=> node >> 30 == 1, over <=> node >= 2^31; after the leaf phase the walk continues at the word 7
  * the leaf's visit loaded (oct_skip).  The node's magnitude for the filter's margin comes from the bounds themselves (three
  * v_max3 with |.| modifiers); its 1.000001 lives in the ray's k2. */
-#ifndef PT_OCT_TAGGED
-#define PT_OCT_TAGGED 1 /* must match the host's image builder (ptx_api.inc); 0: the record of round 4 */
-#endif
+/* (The record of round 4 -- six bounds as stored, `rhs | axis << 30` / packed leaf word, skip link -- and the first tagged record with
+ * un-offset links were this layout's A/B partners: profiles/r05_ab_oct_tagged.txt, r05_ab_oct_preoffset.txt; removed from the source
+ * once measured, commits b266c1b and 0ff57a4's parent hold them.) */
 #ifndef PT_FILTER_DEBUG
 #define PT_FILTER_DEBUG 0 /* diagnostic builds only (tools/filter_error_study.py): the traverser keeps the u and the margin of its last box test on the
                              per-octant record, and the library gains ptx_debug_filter_error -- not in the product build */
 #endif
-#ifndef PT_OCT_PREOFFSET
-#define PT_OCT_PREOFFSET 1 /* (with PT_OCT_TAGGED; must match the host builder; 0: links are node indices, as in the first tagged record) the links of octant o's records are record numbers in the whole image
-                              (o * n_nodes + k) and so is the walk's `node`: a visit's address is ONE multiply-add instead of add, shift, add at the
-                              head of its chain; the binary64 fallback subtracts the octant's base again */
-#endif
+/* Links are PRE-OFFSET: the links of octant o's records are record numbers in the whole image (o * n_nodes + k) and so is the walk's
+ * `node`: a visit's address is one 32-bit shift beside the image's scalar base (the image is smaller than 4 GiB: the host builds it
+ * only then) instead of add, 64-bit shift, 64-bit add at the head of its chain; the binary64 fallback subtracts the octant's base. */
 #define PT_OCT_END 0x80000000u
 #define PT_OCT_LEAF_TAG 0x40000000u
 
@@ -584,7 +582,7 @@ struct PtTraverser {
   /* TAGGED (the LDS image, layout 3): `node` carries the walk's control state in its two low bits (PT_SWZ_TAG_*), `walking` and
    * `leaf_n` are not used between the leaf phases; `lkx` = word 6 of the node visited last (a leaf's first slot | real count << 16) */
   static constexpr bool TAGGED = SWZ && (PT_SWZ_SIGNSEL != 0) && (PT_SWZ_TAGGED != 0);
-  static constexpr bool OTAG = OCT && (PT_OCT_TAGGED != 0); /* the per-octant record with tagged links (PT_OCT_TAGGED) */
+  static constexpr bool OTAG = OCT; /* the per-octant record: tagged, pre-offset links */
   static constexpr bool TAGS = TAGGED || OTAG;
   uint32_t node;
   mutable uint32_t lkx;
@@ -713,7 +711,7 @@ struct PtTraverser {
     node = SWZ ? sv.swz_root : ((G32 && !OCT && sv.has_top) ? PT_TOP_FLAG : 0u); /* the root (slot 0 of the top image) */
     walking = sc.n_nodes > 0;
     if (TAGGED && sc.n_nodes <= 0) node = PT_SWZ_END;
-    if (OTAG && PT_OCT_PREOFFSET) node = skip_off; /* the root's record of this ray's octant */
+    if (OTAG) node = skip_off; /* the root's record of this ray's octant */
     if (OTAG && sc.n_nodes <= 0) node = PT_OCT_END;
     lkx = 0u;
     leaf_first = 0;
@@ -845,12 +843,20 @@ struct PtTraverser {
     if (FILT) {
       uint4 w0, w1;
       float mag;
-      if (OTAG) { /* nd is the node's index; the octant's tagged record (PT_OCT_TAGGED): near xyz, far xyz, hit link, miss link */
-        /* PT_OCT_PREOFFSET: nd is the record's number in the whole image; the image is smaller than 4 GiB (the host builds it only then),
-         * so the byte offset is a 32-bit shift and the load takes it beside the scalar base: one instruction ahead of the loads */
-        const uint4* p = PT_OCT_PREOFFSET ? (const uint4*)(sv.nodes32o + (uint32_t)(nd << 5))
-                                          : (const uint4*)(sv.nodes32o + (size_t)(skip_off + nd) * 32u);
-        const uint4 r0 = p[0], r1 = p[1];
+      if (OTAG) { /* nd is the record's number in the whole image; the octant's tagged record: near xyz, far xyz, hit link, miss link */
+        const uint4* p = (const uint4*)(sv.nodes32o + (uint32_t)(nd << 5)); /* (a 32-bit offset beside the scalar base: one shift ahead of the loads) */
+        const uint4 r0 = p[0];
+        uint4 r1 = p[1];
+#if PT_DIAG_EXTRA_LOADS /* diagnostic builds only: what one / two more 16-byte loads per node visit cost (the record's own line: no new misses) */
+        {
+          const uint4 x0 = p[(nd & 1u) ? -1 : 2];
+          if (x0.x == 0x7fc12345u && x0.w == 0x12345u) r1.x ^= 1u; /* (never true: keeps the load) */
+#if PT_DIAG_EXTRA_LOADS > 1
+          const uint4 x1 = p[(nd & 1u) ? -2 : 3];
+          if (x1.x == 0x7fc12345u && x1.w == 0x12345u) r1.y ^= 1u;
+#endif
+        }
+#endif
         oct_link = r1.z;
         oct_skip = r1.w;
         n_real = (r1.z >> PT_OCT_LEAF_FIRST_BITS) & PT_OCT_LEAF_REAL_MAX; /* (meaningful for a leaf; na / nb are not used by this walk) */
@@ -876,7 +882,7 @@ struct PtTraverser {
             n_undecided++;
             if (pt_lane() == __ffsll((long long)__ballot(1)) - 1) n_wave_fallbacks++;
           }
-          hit = slab64(sv.nodes + (PT_OCT_PREOFFSET ? nd - skip_off : nd)); /* (the canonical node: the octant's base off again) */
+          hit = slab64(sv.nodes + (nd - skip_off)); /* (the canonical node: the octant's base off again) */
         }
         return hit;
       }
@@ -920,29 +926,6 @@ struct PtTraverser {
         nb = (w1.z >> 16) | ((w1.w & 3u) << 30);
         n_real = w1.z >> 16; /* meaningful for leaves only */
         mag = __uint_as_float(w1.w);
-      } else if (OCT) { /* nd is the node's index; the octant's 32-byte record: six binary32 bounds, link, skip */
-        const uint4* p = (const uint4*)(sv.nodes32o + (size_t)(skip_off + nd) * 32u);
-        w0 = p[0];
-        w1 = p[1];
-        const bool leaf = (w1.z >> 30) == PT_NODE_LEAF_AXIS;
-        n_real = (w1.z >> PT_OCT_LEAF_FIRST_BITS) & PT_OCT_LEAF_REAL_MAX;
-        na = leaf ? (w1.z & ((1u << PT_OCT_LEAF_FIRST_BITS) - 1u)) : nd + 1u; /* pre-order: the lhs child follows its parent */
-        /* (Leaf.length incl. the Simd_leaf padding to a multiple of 4, main.ml:179-186: for the work counter only) */
-        nb = leaf ? ((MODE == PT_MODE_SIMD ? ((n_real + 3u) & ~3u) : n_real) | (PT_NODE_LEAF_AXIS << 30)) : w1.z;
-        oct_skip = w1.w;
-#if PT_DIAG_EXTRA_LOADS /* diagnostic builds only: what one / two more 16-byte loads per node visit cost (the record's own line: no new misses) */
-        {
-          const uint4 x0 = p[(nd & 1u) ? -1 : 2];
-          if (x0.x == 0x7fc12345u && x0.w == 0x12345u) w1.x ^= 1u; /* (never true: keeps the load) */
-#if PT_DIAG_EXTRA_LOADS > 1
-          const uint4 x1 = p[(nd & 1u) ? -2 : 3];
-          if (x1.x == 0x7fc12345u && x1.w == 0x12345u) w1.y ^= 1u;
-#endif
-        }
-#endif
-        mag = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(__uint_as_float(w0.x)), __builtin_fabsf(__uint_as_float(w0.y))),
-                                              __builtin_fmaxf(__builtin_fabsf(__uint_as_float(w0.z)), __builtin_fabsf(__uint_as_float(w0.w)))),
-                              __builtin_fmaxf(__builtin_fabsf(__uint_as_float(w1.x)), __builtin_fabsf(__uint_as_float(w1.y)))) * 1.000001f;
       } else { /* nd is the node's index; 32-byte global image: six binary32 bounds, a, b (leaf b: count | real << 15 | tag) */
         if (nd & PT_TOP_FLAG) { /* ... or PT_TOP_FLAG | byte offset into the LDS copy of the tree's top: same words */
           const uint4* p = (const uint4*)(sv.top + (nd & (PT_TOP_FLAG - 1u)));
@@ -1016,7 +999,7 @@ struct PtTraverser {
 #else
     if (SWZ) skip = (uint32_t)*(const uint16_t*)(sv.swz_nodes + node + skip_off);
 #endif
-    else if (!THREAD32 || OCT) skip = 0u; /* OCT: the link arrives with the node's record (test_box) */
+    else if (!THREAD32) skip = 0u;
     else if (node & PT_TOP_FLAG) { /* top image: 16-bit byte offsets, a top node's successor is a top node */
       const uint32_t s16 = (uint32_t)*(const uint16_t*)(sv.top + (node & (PT_TOP_FLAG - 1u)) + 32u + 2u * dirs);
       skip = s16 == 0xffffu ? 0xffffffffu : (PT_TOP_FLAG | s16);
@@ -1056,7 +1039,6 @@ struct PtTraverser {
     }
 #endif
     const bool hit = test_box(sv, node, na, nb, n_real);
-    if (OCT) skip = oct_skip;
     if (hit) {
       const uint32_t axis = nb >> 30;
       if (axis == PT_NODE_LEAF_AXIS) {
@@ -3184,7 +3166,7 @@ __global__ __launch_bounds__(256) void k_filter_error(PtSceneDev sc, long long n
   tr.update_t32();
   const uint32_t k = (uint32_t)nodes[i];
   uint32_t na, nb, nr;
-  const bool final_hit = tr.test_box(sv, PT_OCT_PREOFFSET ? tr.skip_off + k : k, na, nb, nr);
+  const bool final_hit = tr.test_box(sv, tr.skip_off + k, na, nb, nr);
   const float u = tr.dbg_u, m2 = tr.dbg_m2;
   const PtNode* np = sc.nodes + k;
   const V3 inv = v3(1.0 / d.x, 1.0 / d.y, 1.0 / d.z);
