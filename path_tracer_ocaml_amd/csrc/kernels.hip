@@ -444,7 +444,7 @@ struct PtThreadOctTag {};
  * v_max3 with |.| modifiers); its 1.000001 lives in the ray's k2. */
 /* (The record of round 4 -- six bounds as stored, `rhs | axis << 30` / packed leaf word, skip link -- and the first tagged record with
  * un-offset links were this layout's A/B partners: profiles/r05_ab_oct_tagged.txt, r05_ab_oct_preoffset.txt; removed from the source
- * once measured, commits b266c1b and 0ff57a4's parent hold them.) */
+ * once measured; commit afabea1 is the last whose source holds both alternates.) */
 #ifndef PT_FILTER_DEBUG
 #define PT_FILTER_DEBUG 0 /* diagnostic builds only (tools/filter_error_study.py): the traverser keeps the u and the margin of its last box test on the
                              per-octant record, and the library gains ptx_debug_filter_error -- not in the product build */
