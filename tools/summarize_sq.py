@@ -223,6 +223,17 @@ if tr:
                 return b / frames if timed(k) else (b / frames_all if every_frame(k) else 0.0)
             entry["frames_profiled"] = frames
             entry["frames_profiled_incl_counting"] = frames_all
+            # the same count a second way -- the timed walk launches that are NOT camera-ray launches, (depth - 1) x batches per frame
+            # in the one-launch-per-bounce schedule -- so that a change of the launch pattern cannot skew the bytes per step unnoticed
+            # again (a solo run, PTX_SOLO_ENTRIES, returns early from later launches but still issues them)
+            sec_timed = sum(e["launches"] for k, e in out["kernels"].items() if walk(k) and not is_primary(k) and is_timed_trace(k) and e.get("launches"))
+            if depth > 1 and sec_timed:
+                frames_check = sec_timed / (batches * (depth - 1))
+                entry["frames_profiled_check"] = frames_check
+                if abs(frames_check - frames) > 0.01 * frames:
+                    entry["frames_inconsistent"] = True
+                    print(f"WARNING: frames of the profiled run: {frames} by camera-ray launches, {frames_check} by the other walk launches -- "
+                          f"hbm_bytes_per_step is not to be trusted", file=sys.stderr)
             entry["frames_from"] = "camera-ray launches of the timed walk kernels / batches per frame"
             entry["hbm_bytes_per_step"] = sum(per_step(k, e) for k, e in out["kernels"].items() if e.get("launches"))
             entry["hbm_bytes_per_step_by_stage"] = {
