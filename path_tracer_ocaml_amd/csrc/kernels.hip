@@ -14,6 +14,10 @@
  * a pool when it holds 64) -- around an LDS copy of the scene where tree and packets fit one, over the per-octant node image in
  * HBM / L2 otherwise; k_trace + k_shade_pool remain for what k_bounce does not cover (ptx_intersect_rays, scenes too large for
  * LDS beside the pools, PTX_FUSED = 0).
+ * Both walks are stackless and their links TAGGED: a visit ends with one select between "what a hit leads to" and "what a miss leads
+ * to", and the walk's control state -- wants a node, holds a leaf, over -- lives in the link's spare bits (PT_SWZ_TAG_* on the LDS
+ * image, the top two bits of a word on the per-octant record).  On Simd_leaf scenes in LDS the node loop itself is gfx950 assembly
+ * (PtTraverser::walk_asm); everything else is HIP C++.
  *
  * Compiled with -ffp-contract=off; every fused multiply-add below is written out exactly where the
  * reference writes Float.fma / _mm256_fmadd_pd.  No MFMA: there is no dense contraction on this path.
