@@ -456,6 +456,13 @@ struct PtThreadOctTag {};
 /* Links are PRE-OFFSET: the links of octant o's records are record numbers in the whole image (o * n_nodes + k) and so is the walk's
  * `node`: a visit's address is one 32-bit shift beside the image's scalar base (the image is smaller than 4 GiB: the host builds it
  * only then) instead of add, 64-bit shift, 64-bit add at the head of its chain; the binary64 fallback subtracts the octant's base. */
+#ifndef PT_OCT_BATCH_FALLBACK
+#define PT_OCT_BATCH_FALLBACK 1 /* (0: evaluated there and then, as until round 5's last change) a lane whose box test the binary32 filter leaves undecided does not stop its
+                                   wave for the ~100 instructions of the binary64 test there and then (22 % of the mesh's wave steps did, for a handful of
+                                   lanes): it leaves the node loop like a lane that holds a leaf, its node tagged PT_OCT_PENDING, and all such lanes take
+                                   the binary64 test TOGETHER after the loop (resolve_pending), before the leaf phase.  Same tests per ray, same order */
+#endif
+#define PT_OCT_PENDING 0xc0000000u /* top bits 11: "the test of node (low 30 bits) awaits its binary64 evaluation"; oct_link / oct_skip hold its links */
 #define PT_OCT_END 0x80000000u
 #define PT_OCT_LEAF_TAG 0x40000000u
 
@@ -601,7 +608,10 @@ struct PtTraverser {
   __device__ __forceinline__ bool holds_leaf() const { return OTAG ? (node >> 30) == 1u : (TAGGED ? (node & PT_SWZ_TAG_LEAF) != 0u : leaf_n > 0); }
   __device__ __forceinline__ unsigned long long holds_leaf_mask() const { return TAGS ? __builtin_amdgcn_ballot_w64(holds_leaf()) : __builtin_amdgcn_sicmp(leaf_n, 0, 38); }
   /* the ray's walk is not over (it wants a node step or holds a leaf) */
-  __device__ __forceinline__ bool alive() const { return OTAG ? node < PT_OCT_END : (TAGGED ? node != PT_SWZ_END : (walking != 0u || leaf_n > 0)); }
+  __device__ __forceinline__ bool alive() const {
+    return OTAG ? (PT_OCT_BATCH_FALLBACK ? (node & PT_OCT_PENDING) != PT_OCT_END : node < PT_OCT_END) : (TAGGED ? node != PT_SWZ_END : (walking != 0u || leaf_n > 0));
+  }
+  __device__ __forceinline__ bool pending() const { return OTAG && PT_OCT_BATCH_FALLBACK && node >= PT_OCT_PENDING; }
   /* ... as a wave mask, where no lane holds a leaf (after the leaf phase: the chunk cut) */
   __device__ __forceinline__ unsigned long long walking_mask() const { return TAGS ? __builtin_amdgcn_ballot_w64(alive()) : __builtin_amdgcn_uicmp(walking, 0u, 33); }
 
@@ -841,7 +851,8 @@ struct PtTraverser {
     return (tnx - lx >= m2 && hx - tfx >= m2) || (tny - ly >= m2 && hy - tfy >= m2) || (tnz - lz >= m2 && hz - tfz >= m2);
   }
   /* Bbox.is_hit of `nd` against the closest hit so far + the node's links (a, b, real slot count) */
-  __device__ __forceinline__ bool test_box(const PtSceneView& sv, uint32_t nd, uint32_t& na, uint32_t& nb, uint32_t& n_real, bool active = true) const {
+  __device__ __forceinline__ bool test_box(const PtSceneView& sv, uint32_t nd, uint32_t& na, uint32_t& nb, uint32_t& n_real, bool active = true,
+                                           bool* defer_undecided = nullptr /* OTAG: set instead of evaluating the binary64 test here */) const {
     const double t_min = 0.0;
     bool hit;
     if (FILT) {
@@ -881,6 +892,11 @@ struct PtTraverser {
         dbg_m2 = m2;
 #endif
         hit = u >= m2;
+        if (defer_undecided) { /* PT_OCT_BATCH_FALLBACK: no branch here at all -- the caller tags the lane (node_step) */
+          *defer_undecided = active && !(__builtin_fabsf(u) >= m2);
+          if (COUNT && *defer_undecided) n_undecided++;
+          return hit;
+        }
         if (active && !(__builtin_fabsf(u) >= m2)) { /* (as below: one divergent branch; a ray the filter does not apply to carries m2 = NaN) */
           if (COUNT) {
             n_undecided++;
@@ -987,6 +1003,13 @@ struct PtTraverser {
     bool descend = false;
     uint32_t na, nb, n_real;
     if (OTAG) { /* the tagged per-octant record: a hit leads to word 6 (near child, or "holds a leaf"), a miss to word 7 */
+      if (PT_OCT_BATCH_FALLBACK) { /* an undecided test: the lane steps out of the walk with its node tagged (resolve_pending) */
+        bool und = false;
+        const bool hit = test_box(sv, node, na, nb, n_real, true, &und);
+        if (COUNT && PT_DIAG == 0 && !und && hit && (oct_link >> 30) == 1u) c_prims += (unsigned long long)(MODE == PT_MODE_SIMD ? ((n_real + 3u) & ~3u) : n_real);
+        node = und ? (node | PT_OCT_PENDING) : (hit ? oct_link : oct_skip);
+        return;
+      }
       const bool hit = test_box(sv, node, na, nb, n_real);
       if (COUNT && PT_DIAG == 0 && hit && (oct_link >> 30) == 1u) c_prims += (unsigned long long)(MODE == PT_MODE_SIMD ? ((n_real + 3u) & ~3u) : n_real);
       node = hit ? oct_link : oct_skip;
@@ -1079,6 +1102,20 @@ struct PtTraverser {
     }
   }
 
+  /* PT_OCT_BATCH_FALLBACK: the binary64 box test of every lane of the wave whose walk stepped out on an undecided filter test, together;
+   * then the visit's select, as node_step would have made it (oct_link / oct_skip are still that visit's words) */
+  __device__ __forceinline__ void resolve_pending(const PtSceneView& sv, unsigned long long& c_prims) {
+    if (pending()) {
+      const uint32_t nd = node & ~PT_OCT_PENDING;
+      if (COUNT && pt_lane() == __ffsll((long long)__ballot(1)) - 1) n_wave_fallbacks++;
+      const bool hit = slab64(sv.nodes + (nd - skip_off)); /* (the canonical node: the octant's base off again) */
+      if (COUNT && PT_DIAG == 0 && hit && (oct_link >> 30) == 1u) {
+        const uint32_t n_real = (oct_link >> PT_OCT_LEAF_FIRST_BITS) & PT_OCT_LEAF_REAL_MAX;
+        c_prims += (unsigned long long)(MODE == PT_MODE_SIMD ? ((n_real + 3u) & ~3u) : n_real);
+      }
+      node = hit ? oct_link : oct_skip;
+    }
+  }
   /* Leaf.intersect on the held leaf (caller checks leaf_n > 0) */
   __device__ __forceinline__ void packet(const PtSceneView& sv, unsigned long long& c_nodes, unsigned long long& c_floor) {
     const double t_min = 0.0;
@@ -1340,6 +1377,7 @@ __device__ __forceinline__ PtTraceResult pt_trace_ray(const PtSceneDev& sc, cons
       tr.node_step(sv, stack, c_nodes, c_prims);
     }
     }
+    if (tr.OTAG && PT_OCT_BATCH_FALLBACK) tr.resolve_pending(sv, c_prims); /* (a lane it lets into a leaf takes part in the leaf phase below) */
     if (COUNT && PT_DIAG == 6 && !ORIGIN_ZERO) { /* (diagnostic build: ticks the wave spends in the leaf phase, into c_prims; lane 0's copy is kept) */
       __builtin_amdgcn_sched_barrier(0);
       const unsigned long long t0_ = __builtin_readcyclecounter();
