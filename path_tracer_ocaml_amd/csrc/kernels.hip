@@ -404,13 +404,6 @@ typedef unsigned int pt_u2 __attribute__((ext_vector_type(2), aligned(4)));
 #endif
 #define PT_SWZ_TAG_LEAF 1u
 #define PT_SWZ_TAG_END 2u
-#ifndef PT_LDS_BATCH_FALLBACK
-#define PT_LDS_BATCH_FALLBACK 0 /* (1 once measured and through the suite) Array_leaf kernels on LDS scenes (the C++ node loop): a lane whose box test
-                                   neither the filter nor the nested-interval rule decides leaves the loop with PT_SWZ_PENDING set in its node REGISTER
-                                   (links are 16-bit values: bit 16 of the register is free) and all such lanes take the binary64 test together after
-                                   the loop -- what PT_OCT_BATCH_FALLBACK does for the walk from HBM / L2 (5.6 % of cornell's wave steps stopped for it) */
-#endif
-#define PT_SWZ_PENDING 0x10000u
 /* doubles per sphere slot in the LDS copy: 4 used ({x, y, z, r}) + padding.  With 4 (8 words) a slot starts in 8 of the 64 banks
  * only; with 6 (12 words) in 16.  Global memory keeps 4. */
 #ifndef PT_LDS_SPH_DOUBLES
@@ -602,13 +595,12 @@ struct PtTraverser {
   static constexpr bool TAGGED = SWZ && (PT_SWZ_SIGNSEL != 0) && (PT_SWZ_TAGGED != 0);
   static constexpr bool OTAG = OCT; /* the per-octant record: tagged, pre-offset links */
   static constexpr bool TAGS = TAGGED || OTAG;
-  static constexpr bool LDEFER = TAGGED && MODE == PT_MODE_ARRAY && (PT_LDS_BATCH_FALLBACK != 0); /* (Simd_leaf scenes run walk_asm, which leaves for node_step instead) */
   uint32_t node;
   mutable uint32_t lkx;
   uint32_t lkx_diag = 0u, sdiag = 0u; /* (PT_DIAG_VISIT_*) */
   uint32_t walking; /* 0 / 1: an integer, so that "wants a node step" is ONE unsigned comparison (walking > leaf_n) */
   int leaf_first, leaf_n;
-  __device__ __forceinline__ bool wants_node() const { return OTAG ? node < PT_OCT_LEAF_TAG : (TAGGED ? (node & (LDEFER ? (PT_SWZ_PENDING | 3u) : 3u)) == 0u : walking > (uint32_t)leaf_n); }
+  __device__ __forceinline__ bool wants_node() const { return OTAG ? node < PT_OCT_LEAF_TAG : (TAGGED ? (node & 3u) == 0u : walking > (uint32_t)leaf_n); }
   /* the same as a wave mask, straight from the comparison: the ballot builtin of the very expression the branch tests lets the
    * compiler use ONE v_cmp for both (HIP's __ballot of a boolean that is also branched on costs two more vector instructions
    * per turn; __builtin_amdgcn_uicmp a second compare); 38 = signed greater than, 33 = not equal */
@@ -619,7 +611,7 @@ struct PtTraverser {
   __device__ __forceinline__ bool alive() const {
     return OTAG ? (PT_OCT_BATCH_FALLBACK ? (node & PT_OCT_PENDING) != PT_OCT_END : node < PT_OCT_END) : (TAGGED ? node != PT_SWZ_END : (walking != 0u || leaf_n > 0));
   }
-  __device__ __forceinline__ bool pending() const { return (OTAG && PT_OCT_BATCH_FALLBACK && node >= PT_OCT_PENDING) || (LDEFER && (node & PT_SWZ_PENDING) != 0u); }
+  __device__ __forceinline__ bool pending() const { return OTAG && PT_OCT_BATCH_FALLBACK && node >= PT_OCT_PENDING; }
   /* ... as a wave mask, where no lane holds a leaf (after the leaf phase: the chunk cut) */
   __device__ __forceinline__ unsigned long long walking_mask() const { return TAGS ? __builtin_amdgcn_ballot_w64(alive()) : __builtin_amdgcn_uicmp(walking, 0u, 33); }
 
@@ -937,15 +929,12 @@ struct PtTraverser {
         if (active && !(__builtin_fabsf(u) >= m2)) {
           const bool nested = nested_hit(tnx, tfx, tny, tfy, tnz, tfz, m2);
           if (nested) hit = true;
-          else if (defer_undecided) { /* PT_LDS_BATCH_FALLBACK: the caller tags the lane, the binary64 test comes after the loop (resolve_pending) */
-            if (COUNT) n_undecided++;
-            *defer_undecided = true;
-          } else {
+          else {
             if (COUNT) n_undecided++;
             const uint32_t k64 = (nd - sv.swz_root) / PT_SWZ_NODE_BYTES;
             hit = sv.nodes64 ? slab64(sv.nodes64 + (size_t)k64 * 6u) : slab64(sv.nodes + k64); /* (wave-uniform choice) */
           }
-          if (COUNT && !defer_undecided && __ballot(!nested) != 0 && pt_lane() == __ffsll((long long)__ballot(1)) - 1) n_wave_fallbacks++;
+          if (COUNT && __ballot(!nested) != 0 && pt_lane() == __ffsll((long long)__ballot(1)) - 1) n_wave_fallbacks++;
         }
         return hit;
       }
@@ -1050,12 +1039,7 @@ struct PtTraverser {
 #else
       const uint32_t near_c = (uint32_t)*(const uint16_t*)(sv.swz_nodes + node + skip_off + 16u);
 #endif
-      bool und = false;
-      const bool hit = LDEFER ? test_box(sv, node, na, nb, n_real, true, &und) : test_box(sv, node, na, nb, n_real);
-      if (LDEFER && und) { /* (rare) the visit's select waits for the binary64 test: resolve_pending reads the links again */
-        node |= PT_SWZ_PENDING;
-        return;
-      }
+      const bool hit = test_box(sv, node, na, nb, n_real);
       if (TAGGED) {
 #if PT_DIAG_VISIT_VALU || PT_DIAG_VISIT_LDS || PT_DIAG_VISIT_SALU
         for (int k_ = 0; k_ < PT_DIAG_VISIT_VALU; ++k_) asm volatile("v_add_u32 %0, 1, %0" : "+v"(lkx_diag));
@@ -1121,24 +1105,6 @@ struct PtTraverser {
   /* PT_OCT_BATCH_FALLBACK: the binary64 box test of every lane of the wave whose walk stepped out on an undecided filter test, together;
    * then the visit's select, as node_step would have made it (oct_link / oct_skip are still that visit's words) */
   __device__ __forceinline__ void resolve_pending(const PtSceneView& sv, unsigned long long& c_prims) {
-#if PT_SWZ_SIGNSEL
-    if (LDEFER) { /* the LDS image: the node's address is the register's low 16 bits; its links are read again (a rare path) */
-      if (pending()) {
-        const uint32_t nd = node & 0xffffu;
-        if (COUNT && pt_lane() == __ffsll((long long)__ballot(1)) - 1) n_wave_fallbacks++;
-        const uint32_t k64 = (nd - sv.swz_root) / PT_SWZ_NODE_BYTES;
-        const bool hit = sv.nodes64 ? slab64(sv.nodes64 + (size_t)k64 * 6u) : slab64(sv.nodes + k64); /* (wave-uniform choice) */
-        const uint32_t skip = (uint32_t)*(const __attribute__((address_space(3))) uint16_t*)PT_LDS_AT(nd + skip_off + PT_SWZ_OFF_SKIP);
-        const uint32_t near_c = (uint32_t)*(const __attribute__((address_space(3))) uint16_t*)PT_LDS_AT(nd + skip_off + PT_SWZ_OFF_NEAR);
-        if (COUNT && PT_DIAG == 0 && hit && (near_c & PT_SWZ_TAG_LEAF)) {
-          const uint32_t n_real = lkx >> 16; /* (the leaf word of this very visit: test_box loaded it) */
-          c_prims += (unsigned long long)(MODE == PT_MODE_SIMD ? ((n_real + 3u) & ~3u) : n_real);
-        }
-        node = hit ? near_c : skip;
-      }
-      return;
-    }
-#endif
     if (pending()) {
       const uint32_t nd = node & ~PT_OCT_PENDING;
       if (COUNT && pt_lane() == __ffsll((long long)__ballot(1)) - 1) n_wave_fallbacks++;
@@ -1411,7 +1377,7 @@ __device__ __forceinline__ PtTraceResult pt_trace_ray(const PtSceneDev& sc, cons
       tr.node_step(sv, stack, c_nodes, c_prims);
     }
     }
-    if ((tr.OTAG && PT_OCT_BATCH_FALLBACK) || tr.LDEFER) tr.resolve_pending(sv, c_prims); /* (a lane it lets into a leaf takes part in the leaf phase below) */
+    if (tr.OTAG && PT_OCT_BATCH_FALLBACK) tr.resolve_pending(sv, c_prims); /* (a lane it lets into a leaf takes part in the leaf phase below) */
     if (COUNT && PT_DIAG == 6 && !ORIGIN_ZERO) { /* (diagnostic build: ticks the wave spends in the leaf phase, into c_prims; lane 0's copy is kept) */
       __builtin_amdgcn_sched_barrier(0);
       const unsigned long long t0_ = __builtin_readcyclecounter();
