@@ -84,7 +84,8 @@ def leaf_boxes(g_scene):
 
 SCALES = [2.0 ** -20, 2.0 ** -7, 1.0, 2.0 ** 9, 2.0 ** 21]
 # a soak run (tools/round_record.sh) adds PTX_FUZZ_SEEDS fresh seeds to the two LDS-resident soups below
-SOAK = [(100 + k, SCALES[k % len(SCALES)]) for k in range(int(os.environ.get("PTX_FUZZ_SEEDS", "0")))]
+# (PTX_FUZZ_SEED0 moves the range: a second soak takes other seeds than the first)
+SOAK = [(100 + k, SCALES[k % len(SCALES)]) for k in range(int(os.environ.get("PTX_FUZZ_SEED0", "0")), int(os.environ.get("PTX_FUZZ_SEED0", "0")) + int(os.environ.get("PTX_FUZZ_SEEDS", "0")))]
 
 
 @pytest.mark.parametrize("seed,scale", [(s, sc) for s, sc in enumerate(SCALES)] + [(7, 1.0), (8, 2.0 ** 21), (9, 2.0 ** -20)] + SOAK)

@@ -401,7 +401,8 @@ def test_gpu_bvh_build_equals_oracle_tree(P, oracle, name):
 
 
 # ---------------------------------------------------------------- seeded sweep over render configurations
-@pytest.mark.parametrize("seed", range(int(os.environ.get("PTX_TEST_SEEDS", "12"))))  # a soak run sets a few hundred
+# a soak run sets a few thousand (PTX_TEST_SEEDS); PTX_TEST_SEED0 moves the range, so that a second soak does not repeat the first
+@pytest.mark.parametrize("seed", range(int(os.environ.get("PTX_TEST_SEED0", "0")), int(os.environ.get("PTX_TEST_SEED0", "0")) + int(os.environ.get("PTX_TEST_SEEDS", "12"))))
 def test_random_configs_raw_sums_bitwise(P, oracle, seed, monkeypatch):
     """Random (scene, size, spp, depth, batching, band sharding, trace-kernel choice): the raw per-pixel sums are the
     oracle's bit for bit whatever way the work is cut up."""
